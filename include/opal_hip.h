@@ -1,0 +1,132 @@
+/*
+ * opal_hip.h -- C-ABI of libopal_hip.so: the MI355X (gfx950) implementation of Opal's hot path
+ * (fragment sampling -> LDPC spaced-k-mer features -> VW-style hashing -> one-against-all scoring).
+ *
+ * The reference (yunwilliamyu/opal) has no FFI: the path sits behind three in-process Python call sites and
+ * one subprocess protocol.  Each entry point below names the reference interface it replaces (file:line under
+ * the reference tree).  INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success or a negative OPAL_E* code;
+ *     opal_last_error(ctx) (ctx may be NULL for handle-less calls) returns a NUL-terminated message.
+ *   - pointers named d_* are DEVICE pointers (HBM) on the ctx's device; all others are host pointers.
+ *   - device work is enqueued on the ctx's HIP stream and is asynchronous; opal_sync() waits for it.
+ *   - one ctx per GPU, not thread-safe; different ctxs may be driven concurrently.
+ *
+ * Fragment batch layout in HBM ("reads"):
+ *   d_frag_off[i]  byte offset of fragment i inside d_reads
+ *   d_frag_len[i]  low 31 bits: length in bases; bit 31 (OPAL_RAW_FLAG) set -> the fragment is stored as raw
+ *                  ASCII bytes (one per base: anything that is not upper-case A/C/G/T lives here), clear -> it is
+ *                  2-bit packed, 4 bases per byte, base j of the fragment in bits 2*(j&3) of byte j>>2, A=0 C=1 G=2 T=3.
+ */
+#ifndef OPAL_HIP_H
+#define OPAL_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OPAL_OK 0
+#define OPAL_EINVAL (-22)   /* bad argument / shape                      */
+#define OPAL_ENOMEM (-12)   /* host or device allocation failed          */
+#define OPAL_ESTATE (-1)    /* patterns / weights not set yet            */
+#define OPAL_EHIP (-5)      /* a HIP runtime call failed (see last error)*/
+#define OPAL_ERANGE (-34)   /* output capacity too small                 */
+
+#define OPAL_RAW_FLAG 0x80000000u
+#define OPAL_MAX_K 256      /* k-mer length limit                        */
+#define OPAL_MAX_T 64       /* row weight limit                          */
+#define OPAL_MAX_P 64       /* number of patterns limit                  */
+#define OPAL_VW_CONSTANT 11650396u
+
+typedef struct opal_ctx opal_ctx;
+typedef struct opal_rng opal_rng;
+
+/* ---- library / context ------------------------------------------------------------------------------- */
+const char *opal_version(void);
+const char *opal_last_error(const opal_ctx *ctx);
+
+/* stream: the hipStream_t every call of this ctx enqueues on (e.g. torch's current stream); NULL is HIP's
+ * default (null) stream.  The ctx never creates or destroys streams.                                       */
+int opal_ctx_create(int device_id, void *stream, opal_ctx **out);
+int opal_ctx_destroy(opal_ctx *ctx);
+int opal_sync(opal_ctx *ctx);
+void *opal_ctx_stream(opal_ctx *ctx);
+
+/* Replaces fasta2skm.create_pattern_getters (util/fasta2skm.py:120-134): pos is the P x t table of positions
+ * read from patterns.txt (row-major, each 0 <= pos < k).  Needs k % t == 0 (fasta2skm.py:125).              */
+int opal_set_patterns(opal_ctx *ctx, const int32_t *pos, int P, int t, int k);
+
+/* Replaces `vw -t -i <model>` loading its regressor (opal.py:449-451).  w is the compact table of the
+ * 2^bits `w` components (one float per VW weight slot), K the --oaa class count (opal.py:311).  The ctx keeps
+ * a private device copy padded by K floats so that rows never wrap.  opal_load_weights takes a HOST table,
+ * opal_set_weights_device a DEVICE table (copied device-to-device).                                          */
+int opal_load_weights(opal_ctx *ctx, const float *w, uint64_t n_slots, int K, int bits);
+int opal_set_weights_device(opal_ctx *ctx, const float *d_w, uint64_t n_slots, int K, int bits);
+
+/* VW behaviours that differ between versions, defaults in brackets:
+ * hash_all [0]: 0 = `--hash strings` (all-digit names are read as numbers), 1 = `--hash all`;
+ * add_constant [1]: append the bias feature 11650396 after the user features;
+ * clip [1]: clamp every class score to [min_label,max_label] (NaN -> 0) before the argmax [-1, 1].          */
+int opal_set_vw_options(opal_ctx *ctx, int hash_all, int add_constant, int clip, float min_label, float max_label);
+
+/* ---- host-side helpers (no GPU needed) ------------------------------------------------------------- */
+
+/* Packs n sequences (concatenated ASCII in `seqs`, seq_off[n+1]) into the fragment batch layout above.
+ * Call with out==NULL to learn the byte size (*out_bytes); frag_off[n] and frag_len[n] are always written
+ * when non-NULL.  Replaces the text hand-off fasta_reader -> gen_features (util/fasta2skm.py:77-78).        */
+int opal_pack_reads(const uint8_t *seqs, const uint64_t *seq_off, uint64_t n, uint8_t *out, uint64_t out_cap,
+                    uint64_t *frag_off, uint32_t *frag_len, uint64_t *out_bytes);
+
+/* CPython-exact `random` stream (MT19937), the generator drawfrag.py:24,38 and opal.py:363 draw from.       */
+int opal_rng_create(opal_rng **out);
+int opal_rng_destroy(opal_rng *rng);
+/* random.seed(int): limbs = 32-bit little-endian limbs of abs(seed), n_limbs >= 1.                          */
+int opal_rng_seed(opal_rng *rng, const uint32_t *limbs, int n_limbs);
+/* random.randint(0, n-1) -> *out                                                                          */
+int opal_rng_randbelow(opal_rng *rng, uint64_t n, uint64_t *out);
+/* Replaces drawfrag.main_not_commandline's sampling loop (util/drawfrag.py:27-49, --atgc off as opal.py
+ * always calls it): for each genome in order draws fragments until coverage*len is covered.  Writes at most
+ * cap (position, genome index) pairs; *n_out is the number drawn (OPAL_ERANGE if it exceeds cap; the stream
+ * is consumed either way, re-seed before retrying).                                                       */
+int opal_sample_positions(opal_rng *rng, const uint64_t *genome_len, uint64_t n_genomes, uint64_t frag_len,
+                          double coverage, uint64_t *out_pos, uint32_t *out_genome, uint64_t cap, uint64_t *n_out);
+/* random.shuffle of [0..n) continuing the same stream (opal.py:363): perm must hold 0..n-1 on entry.       */
+int opal_rng_shuffle(opal_rng *rng, uint64_t *perm, uint64_t n);
+
+/* ---- device entry points ----------------------------------------------------------------------------- */
+
+/* Per-fragment feature counts as an exclusive prefix sum: d_out_off[i] = sum_{j<i} F_j, d_out_off[n] = total,
+ * F_j = max(0,len_j-k+1) * P * (reverse?2:1)  (get_all_substrings, util/fasta_functions.py:53-54).          */
+int opal_feature_offsets(opal_ctx *ctx, const uint32_t *d_frag_len, uint64_t n, int reverse, uint64_t *d_out_off);
+
+/* Emit mode. Replaces fasta2skm.gen_features + VW's name hashing for a whole batch
+ * (util/fasta2skm.py:137-141,78-80; vw parse of the line written at opal.py:366-367,468-469):
+ * d_out_idx[d_out_off[i] + f] = hash(name of feature f of fragment i) & (2^bits - 1), features in the
+ * reference's order (forward strand window-major / pattern-minor, then the reverse complement).
+ * d_out_off must have been filled by opal_feature_offsets with the same `reverse`.                          */
+int opal_features(opal_ctx *ctx, const uint8_t *d_reads, uint64_t reads_bytes, const uint64_t *d_frag_off,
+                  const uint32_t *d_frag_len, uint64_t n, int reverse, int bits, const uint64_t *d_out_off,
+                  uint32_t *d_out_idx);
+
+/* Debug twin of opal_features: writes the t gathered characters of every feature (the feature NAME without
+ * its decimal pattern suffix) so that the host can rebuild the reference's VW text line byte for byte
+ * (util/fasta2skm.py:81-82).  d_out_names holds t bytes per feature at (d_out_off[i]+f)*t.                  */
+int opal_feature_names(opal_ctx *ctx, const uint8_t *d_reads, uint64_t reads_bytes, const uint64_t *d_frag_off,
+                       const uint32_t *d_frag_len, uint64_t n, int reverse, const uint64_t *d_out_off,
+                       uint8_t *d_out_names);
+
+/* Fused predict. Replaces fasta2skm.main_generator piped into `vw -t -i model -p preds` (opal.py:449-469):
+ * d_out_class[i] = 1-based VW class of fragment i (what vw writes to the -p file), d_out_scores (optional,
+ * may be NULL) receives the K per-class scores of every fragment, row-major [n][K].                         */
+int opal_predict(opal_ctx *ctx, const uint8_t *d_reads, uint64_t reads_bytes, const uint64_t *d_frag_off,
+                 const uint32_t *d_frag_len, uint64_t n, int reverse, int32_t *d_out_class, float *d_out_scores);
+
+/* Name of the scoring-kernel variant opal_predict would launch for the current K (for profiles/bench).   */
+const char *opal_predict_kernel_name(opal_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPAL_HIP_H */

@@ -1,0 +1,41 @@
+// Internal declarations shared by the host-side and device-side halves of libopal_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "opal_hip.h"
+
+struct opal_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 256;
+    // patterns (util/fasta2skm.py:120-134)
+    int k = 0, P = 0, t = 0;
+    uint8_t *d_pos = nullptr;  // P*t positions, each < k <= 256
+    // weights (VW regressor, compact `w` components)
+    float *d_w = nullptr;      // 2^bits + pad floats: first K(+3) floats mirrored at the end so rows never wrap
+    uint64_t w_alloc_floats = 0;
+    uint64_t n_slots = 0;
+    int K = 0, bits = 0;
+    // VW switches
+    int hash_all = 0, add_constant = 1, clip = 1;
+    float min_label = -1.0f, max_label = 1.0f;
+    // scratch for the offsets scan
+    uint64_t *d_block_sums = nullptr;
+    uint64_t block_sums_cap = 0;
+    std::string err;
+};
+
+namespace opal {
+void set_global_error(const std::string &s);
+int fail(opal_ctx *ctx, int code, const std::string &msg);
+}  // namespace opal
+
+#define OPAL_HIP_CHECK(ctx, call)                                                                              \
+    do {                                                                                                       \
+        hipError_t e__ = (call);                                                                               \
+        if (e__ != hipSuccess)                                                                                 \
+            return opal::fail((ctx), OPAL_EHIP, std::string(#call) + ": " + hipGetErrorString(e__));            \
+    } while (0)

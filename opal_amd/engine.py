@@ -1,0 +1,231 @@
+"""Host-side driver of libopal_hip.so: packs fragments, owns the per-GPU context, moves buffers with torch.
+
+torch is plumbing only (device memory, streams); every computation on the hot path happens inside
+libopal_hip.so (hand-written HIP kernels for gfx950) through the C-ABI of include/opal_hip.h.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+
+__all__ = ["PackedReads", "Rng", "Engine", "parse_patterns"]
+
+
+def parse_patterns(lines, kmer):
+    """Mirror of fasta2skm.create_pattern_getters (reference util/fasta2skm.py:120-134): returns the [P, t]
+    int32 table of positions.  `lines` is file.readlines() of patterns.txt, or None for the identity k-mer.
+    Raises AssertionError on a malformed file, exactly where the reference asserts."""
+    if lines:
+        num_hash, row_weight = [int(x) for x in lines[0].split()[:2]]
+        assert kmer % row_weight == 0
+        rows = []
+        for i in range(num_hash):
+            row = [int(x) for x in lines[1 + i].split()]
+            assert len(row) == row_weight
+            rows.append(row)
+    else:
+        rows = [list(range(kmer))]
+    return np.ascontiguousarray(np.array(rows, dtype=np.int32))
+
+
+class PackedReads:
+    """A fragment batch in the layout of include/opal_hip.h (host copy): 2-bit packed A/C/G/T, raw bytes else."""
+
+    def __init__(self, data, off, length):
+        self.data, self.off, self.len = data, off, length
+        self.n = int(len(off))
+
+    @staticmethod
+    def from_blob(blob: np.ndarray, seq_off: np.ndarray):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+        n = len(seq_off) - 1
+        L = lib()
+        frag_off = np.zeros(max(n, 1), dtype=np.uint64)
+        frag_len = np.zeros(max(n, 1), dtype=np.uint32)
+        nbytes = C.c_uint64(0)
+        check(L.opal_pack_reads(blob.ctypes.data, seq_off.ctypes.data, n, None, 0, frag_off.ctypes.data,
+                                frag_len.ctypes.data, C.byref(nbytes)))
+        out = np.zeros(max(int(nbytes.value), 1), dtype=np.uint8)
+        check(L.opal_pack_reads(blob.ctypes.data, seq_off.ctypes.data, n, out.ctypes.data, out.size, frag_off.ctypes.data,
+                                frag_len.ctypes.data, C.byref(nbytes)))
+        return PackedReads(out[:max(int(nbytes.value), 1)], frag_off[:n], frag_len[:n])
+
+    @staticmethod
+    def from_sequences(seqs):
+        """seqs: iterable of bytes (the text of each record, as fasta_reader would yield it)."""
+        seqs = list(seqs)
+        off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        if seqs:
+            off[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+        blob = np.frombuffer(b"".join(seqs) + b"\0", dtype=np.uint8)
+        return PackedReads.from_blob(blob, off)
+
+    @staticmethod
+    def from_codes(codes: np.ndarray):
+        """codes: uint8 [n, L] of 2-bit base codes (A=0 C=1 G=2 T=3), every fragment the same length."""
+        n, L = codes.shape
+        nb = (L + 3) // 4
+        pad = np.zeros((n, nb * 4), dtype=np.uint8)
+        pad[:, :L] = codes
+        q = pad.reshape(n, nb, 4)
+        data = (q[:, :, 0] | (q[:, :, 1] << 2) | (q[:, :, 2] << 4) | (q[:, :, 3] << 6)).astype(np.uint8).reshape(-1)
+        off = (np.arange(n, dtype=np.uint64) * np.uint64(nb))
+        return PackedReads(np.ascontiguousarray(data), off, np.full(n, L, dtype=np.uint32))
+
+
+class Rng:
+    """CPython-exact `random` stream (what drawfrag.py:24,38 and opal.py:363 consume)."""
+
+    def __init__(self, seed=None):
+        h = C.c_void_p()
+        check(lib().opal_rng_create(C.byref(h)))
+        self._h = h
+        if seed is not None:
+            self.seed(seed)
+
+    def __del__(self):
+        try:
+            lib().opal_rng_destroy(self._h)
+        except Exception:
+            pass
+
+    def seed(self, seed: int):
+        a = abs(int(seed))
+        limbs = []
+        while a:
+            limbs.append(a & 0xFFFFFFFF)
+            a >>= 32
+        arr = np.array(limbs or [0], dtype=np.uint32)
+        check(lib().opal_rng_seed(self._h, arr.ctypes.data, len(arr)))
+
+    def randint(self, a: int, b: int) -> int:
+        out = C.c_uint64()
+        check(lib().opal_rng_randbelow(self._h, b - a + 1, C.byref(out)))
+        return a + int(out.value)
+
+    def sample_positions(self, genome_len, frag_len: int, coverage: float):
+        gl = np.ascontiguousarray(np.asarray(genome_len, dtype=np.uint64))
+        cap = int(sum(int(coverage * int(x) / frag_len) + 2 for x in gl if x >= frag_len)) + 16
+        pos = np.zeros(cap, dtype=np.uint64)
+        gen = np.zeros(cap, dtype=np.uint32)
+        n = C.c_uint64()
+        check(lib().opal_sample_positions(self._h, gl.ctypes.data, len(gl), frag_len, float(coverage), pos.ctypes.data,
+                                          gen.ctypes.data, cap, C.byref(n)))
+        return pos[:n.value], gen[:n.value]
+
+    def shuffle_perm(self, n: int):
+        perm = np.arange(n, dtype=np.uint64)
+        check(lib().opal_rng_shuffle(self._h, perm.ctypes.data, n))
+        return perm
+
+
+class DeviceBatch:
+    def __init__(self, data, off, length, n, nbytes):
+        self.data, self.off, self.len, self.n, self.nbytes = data, off, length, n, nbytes
+
+
+class Engine:
+    """One per GPU.  Mirrors the predict half of opal.py (reference opal.py:449-469) as in-process calls."""
+
+    def __init__(self, device=0, use_torch_stream=True):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("opal_amd.Engine needs a GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream if use_torch_stream else None
+        h = C.c_void_p()
+        check(lib().opal_ctx_create(device, stream, C.byref(h)))
+        self._h = h
+        self.k = self.P = self.t = 0
+        self.K = self.bits = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().opal_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ configuration
+    def set_patterns(self, pos: np.ndarray, k: int):
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        P, t = pos.shape
+        check(lib().opal_set_patterns(self._h, pos.ctypes.data, P, t, k), self._h)
+        self.k, self.P, self.t = k, P, t
+
+    def load_weights(self, w, K: int, bits: int):
+        """w: numpy float32 [2^bits] (host) or a torch cuda float32 tensor of that size."""
+        n_slots = 1 << bits
+        if isinstance(w, np.ndarray):
+            w = np.ascontiguousarray(w, dtype=np.float32)
+            assert w.size == n_slots
+            check(lib().opal_load_weights(self._h, w.ctypes.data, n_slots, K, bits), self._h)
+        else:
+            assert w.is_cuda and w.dtype == self.torch.float32 and w.numel() == n_slots and w.is_contiguous()
+            check(lib().opal_set_weights_device(self._h, w.data_ptr(), n_slots, K, bits), self._h)
+        self.K, self.bits = K, bits
+
+    def set_vw_options(self, hash_all=False, add_constant=True, clip=True, min_label=-1.0, max_label=1.0):
+        check(lib().opal_set_vw_options(self._h, int(hash_all), int(add_constant), int(clip), min_label, max_label), self._h)
+
+    def sync(self):
+        check(lib().opal_sync(self._h), self._h)
+
+    def predict_kernel_name(self):
+        return lib().opal_predict_kernel_name(self._h).decode()
+
+    # ------------------------------------------------------------------ data movement (torch plumbing)
+    def upload(self, pr: PackedReads) -> DeviceBatch:
+        t = self.torch
+        data = t.from_numpy(pr.data).to(self.device)
+        off = t.from_numpy(pr.off.view(np.int64)).to(self.device) if pr.n else t.zeros(1, dtype=t.int64, device=self.device)
+        ln = t.from_numpy(pr.len.view(np.int32)).to(self.device) if pr.n else t.zeros(1, dtype=t.int32, device=self.device)
+        return DeviceBatch(data, off, ln, pr.n, int(pr.data.size))
+
+    # ------------------------------------------------------------------ hot path
+    def feature_offsets(self, b: DeviceBatch, reverse: bool):
+        t = self.torch
+        out = t.empty(b.n + 1, dtype=t.int64, device=self.device)
+        check(lib().opal_feature_offsets(self._h, b.len.data_ptr(), b.n, int(reverse), out.data_ptr()), self._h)
+        return out
+
+    def features(self, b: DeviceBatch, reverse: bool, bits: int, offsets=None):
+        """Emit mode: (idx int32-as-uint32 tensor [total], offsets int64 tensor [n+1]) on the device."""
+        t = self.torch
+        if offsets is None:
+            offsets = self.feature_offsets(b, reverse)
+        total = int(offsets[-1].item())
+        idx = t.empty(max(total, 1), dtype=t.int32, device=self.device)
+        check(lib().opal_features(self._h, b.data.data_ptr(), b.nbytes, b.off.data_ptr(), b.len.data_ptr(), b.n,
+                                  int(reverse), bits, offsets.data_ptr(), idx.data_ptr()), self._h)
+        return idx[:total], offsets
+
+    def feature_names(self, b: DeviceBatch, reverse: bool, offsets=None):
+        t = self.torch
+        if offsets is None:
+            offsets = self.feature_offsets(b, reverse)
+        total = int(offsets[-1].item())
+        names = t.empty(max(total * self.t, 1), dtype=t.uint8, device=self.device)
+        check(lib().opal_feature_names(self._h, b.data.data_ptr(), b.nbytes, b.off.data_ptr(), b.len.data_ptr(), b.n,
+                                       int(reverse), offsets.data_ptr(), names.data_ptr()), self._h)
+        return names[:total * self.t].view(total, self.t) if total else names[:0].view(0, self.t), offsets
+
+    def predict(self, b: DeviceBatch, reverse: bool, want_scores=False, out_class=None, out_scores=None):
+        """Fused extract+hash+score: returns (classes int32 [n] (1-based VW ids), scores float32 [n,K] or None)."""
+        t = self.torch
+        if out_class is None:
+            out_class = t.empty(max(b.n, 1), dtype=t.int32, device=self.device)
+        if want_scores and out_scores is None:
+            out_scores = t.empty((max(b.n, 1), self.K), dtype=t.float32, device=self.device)
+        check(lib().opal_predict(self._h, b.data.data_ptr(), b.nbytes, b.off.data_ptr(), b.len.data_ptr(), b.n,
+                                 int(reverse), out_class.data_ptr(), out_scores.data_ptr() if want_scores else None), self._h)
+        return out_class[:b.n], (out_scores[:b.n] if want_scores else None)

@@ -1,0 +1,97 @@
+"""Mirror of the reference's util/fasta2skm.py interface on top of the GPU engine.
+
+Same names, argument meaning and error behaviour as the reference module:
+  update_dictionary(labels, dico_file)      util/fasta2skm.py:19-44
+  create_pattern_getters(lines, kmer)       util/fasta2skm.py:120-134  (returns the [P,t] position table)
+  main_generator(args)                      util/fasta2skm.py:47-84    (yields the same VW text lines)
+The fast path never builds text: opal.predict() feeds packed fragments straight to Engine.predict().  The text
+generator exists for parity tests and for `--dump-vw-text`; the characters of every feature are gathered on the
+GPU (opal_feature_names), only the string formatting happens here.
+"""
+import itertools
+import os
+
+import numpy as np
+
+from .engine import Engine, PackedReads, parse_patterns
+from .fasta_functions import fasta_reader
+
+__all__ = ["update_dictionary", "create_pattern_getters", "main_generator", "vw_text_lines", "load_labels"]
+
+create_pattern_getters = parse_patterns
+
+
+def update_dictionary(labels, dico_file):
+    """Updates the dictionary file converting labels to vwid with an iterator over new labels."""
+    label2vwid = {}
+    vwidset = set()
+    if os.path.isfile(dico_file):
+        with open(dico_file, "r") as df:
+            for line in df.readlines():
+                label, vwid_str = line.strip().split()[:2]
+                vwid = int(vwid_str)
+                label2vwid[label] = vwid
+                vwidset.add(vwid)
+    for line in labels:
+        label = line.rstrip("\n")
+        if label not in label2vwid:
+            vwid = 1 if len(vwidset) == 0 else max(vwidset) + 1
+            label2vwid[label] = vwid
+            vwidset.add(vwid)
+    with open(dico_file, "w") as df:
+        for label, vwid in list(label2vwid.items()):
+            df.write("{}\t{}\n".format(label, vwid))
+    return label2vwid
+
+
+def vw_text_lines(engine: Engine, seqs, reverse, labels=None, chunk=4096):
+    """VW text lines (bytes, each ending in '\\n') for sequences `seqs` (list of bytes): '<label> | f f f\\n' with
+    f = <t gathered chars><pattern index> (util/fasta2skm.py:81-82,140).  labels: iterable or None (-> 1)."""
+    labels = iter(labels) if labels is not None else itertools.repeat(1)
+    P, t = engine.P, engine.t
+    suffix = [str(i).encode() for i in range(P)]
+    out = []
+    for c0 in range(0, len(seqs), chunk):
+        part = seqs[c0:c0 + chunk]
+        batch = engine.upload(PackedReads.from_sequences(part))
+        names, off = engine.feature_names(batch, reverse)
+        names = names.cpu().numpy()
+        off = off.cpu().numpy()
+        for i in range(len(part)):
+            rows = names[off[i]:off[i + 1]]
+            feats = [rows[f].tobytes() + suffix[f % P] for f in range(rows.shape[0])]
+            out.append(("%s | " % next(labels)).encode() + b" ".join(feats) + b"\n")
+    return out
+
+
+def load_labels(args):
+    """The label stream of main_generator (util/fasta2skm.py:55-60,70-74)."""
+    if args.taxid:
+        if not args.dico:
+            raise ValueError("If --taxid is set, then so must be --dico")
+        with open(args.taxid, "r") as taxid_file:
+            label2vwid = update_dictionary(taxid_file, args.dico)
+        with open(args.taxid, "r") as taxid_file:
+            return [label2vwid[l.rstrip("\n")] for l in taxid_file]
+    return None
+
+
+def main_generator(args, engine=None):
+    """Yields the VW text lines the reference yields for the same Namespace(input, taxid, kmer, dico, pattern,
+    reverse).  Needs a GPU: the gathers run in libopal_hip.so."""
+    if not args.input or not args.kmer:
+        raise ValueError("fasta2skm requires input and kmer arguments")
+    labels = load_labels(args)
+    if args.pattern:
+        with open(args.pattern, "r") as pattern_file:
+            file_contents = pattern_file.readlines()
+    else:
+        file_contents = None
+    pos = create_pattern_getters(file_contents, args.kmer)
+    eng = engine or Engine(0)
+    eng.set_patterns(pos, args.kmer)
+    with open(args.input, "r", encoding="latin-1") as input_file:
+        seqs = [s.encode("latin-1") for _, s in fasta_reader(input_file)]
+    lab = iter(labels) if labels is not None else None
+    for line in vw_text_lines(eng, seqs, bool(args.reverse), lab):
+        yield line.decode("latin-1")

@@ -1,0 +1,231 @@
+"""GPU parity: the HIP path (through the C-ABI of include/opal_hip.h) against the CPU oracle and the
+reference-generated golden vectors.  Bit-exact everywhere: indices/offsets/classes are integers, and the
+fp32 scores are accumulated in the reference's order so they must match the oracle bit for bit.
+
+VW-side rules (addressing, constant, clip, argmax) are checked against the oracle's restatement only:
+"parity unpinned" (no vw binary exists anywhere).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def _load(golden_dir, name):
+    with open(os.path.join(golden_dir, name)) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import opal_amd
+    opal_amd.lib()
+    return opal_amd
+
+
+@pytest.fixture(scope="module")
+def eng(amd):
+    e = amd.Engine(0)
+    yield e
+    e.close()
+
+
+def _patterns(amd, golden_dir, fname, k):
+    if fname is None:
+        return amd.parse_patterns(None, k)
+    with open(os.path.join(golden_dir, fname)) as f:
+        return amd.parse_patterns(f.readlines(), k)
+
+
+def _u32(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+def _rand_seqs(rng, n, L):
+    return [bytes(rng.choice(ACGT, size=L)) for _ in range(n)]
+
+
+# ------------------------------------------------------------------------------ emit mode vs golden
+def test_emit_indices_match_reference_golden(amd, eng, oracle, golden_dir):
+    cases = _load(golden_dir, "skm.json")
+    for c in cases:
+        pos = _patterns(amd, golden_dir, c["pattern"], c["k"])
+        if pos.shape[1] > 64:
+            continue
+        eng.set_patterns(pos, c["k"])
+        seqs = [s for _, s in oracle.fasta_read(c["fasta"].encode("latin-1"))]
+        batch = eng.upload(amd.PackedReads.from_sequences(seqs))
+        want_off = np.concatenate([[0], np.cumsum([len(h) for h in c["h32"]])]).astype(np.int64)
+        for bits in (18, 31, 32):
+            mask = (1 << bits) - 1
+            # golden hashes are pure murmur (sklearn): compare with --hash all ...
+            eng.set_vw_options(hash_all=True)
+            idx, off = eng.features(batch, c["reverse"], bits)
+            assert np.array_equal(off.cpu().numpy(), want_off), c["name"]
+            want = np.array([h & mask for hs in c["h32"] for h in hs], dtype=np.uint32)
+            assert np.array_equal(_u32(idx), want), (c["name"], bits)
+            # ... and the VW default (--hash strings, digit rule) with the oracle
+            eng.set_vw_options(hash_all=False)
+            idx2, _ = eng.features(batch, c["reverse"], bits)
+            oidx, ooff = oracle.features_batch(seqs, c["k"], pos, c["reverse"], min(bits, 32), hash_all=False)
+            assert np.array_equal(_u32(idx2), oidx), (c["name"], bits, "digit rule")
+    eng.set_vw_options()
+
+
+def test_vw_text_lines_rebuilt_from_gpu_names(amd, eng, oracle, golden_dir):
+    """--dump-vw-text path: names gathered on the GPU + host formatting == the reference's lines, byte for byte."""
+    from opal_amd import fasta2skm
+    for c in _load(golden_dir, "skm.json"):
+        pos = _patterns(amd, golden_dir, c["pattern"], c["k"])
+        if pos.shape[1] > 64:
+            continue
+        eng.set_patterns(pos, c["k"])
+        seqs = [s for _, s in oracle.fasta_read(c["fasta"].encode("latin-1"))]
+        lines = fasta2skm.vw_text_lines(eng, seqs, c["reverse"], labels=None)
+        assert [l.decode("latin-1") for l in lines] == c["lines"], c["name"]
+
+
+# ------------------------------------------------------------------------------ fused predict vs oracle
+@pytest.mark.parametrize("K,bits", [(10, 12), (7, 16), (1, 10), (64, 14), (356, 12), (356, 20), (1564, 20), (1563, 18),
+                                    (2050, 18), (4100, 16), (130, 31 - 9)])
+def test_predict_matches_oracle(amd, eng, oracle, golden_dir, K, bits):
+    rng = np.random.default_rng(K * 131 + bits)
+    pos = _patterns(amd, golden_dir, "patterns_k64_t16_m1_s7.txt", 64)
+    eng.set_patterns(pos, 64)
+    seqs = _rand_seqs(rng, 37, 200)
+    seqs[1] = seqs[1].lower()                      # raw path, case quirk of reverse_complement
+    seqs[2] = seqs[2][:17] + b"N" + seqs[2][18:]   # raw path
+    seqs[3] = seqs[3][:63]                         # no features: only the constant
+    seqs[4] = seqs[4][:64]                         # a single window
+    seqs[5] = b""
+    w = (rng.standard_normal(1 << bits) * 0.05).astype(np.float32)
+    eng.load_weights(w, K, bits)
+    batch = eng.upload(amd.PackedReads.from_sequences(seqs))
+    for reverse in (True, False):
+        for (addc, clip) in ((True, True), (True, False), (False, False)):
+            eng.set_vw_options(add_constant=addc, clip=clip, min_label=-0.25, max_label=0.3)
+            cls, sc = eng.predict(batch, reverse, want_scores=True)
+            ocls, osc, _ = oracle.predict(seqs, 64, pos, reverse, w, K, bits, add_constant=addc, clip=clip,
+                                          min_label=-0.25, max_label=0.3)
+            assert np.array_equal(sc.cpu().numpy(), osc), (K, bits, reverse, addc, clip)
+            assert np.array_equal(cls.cpu().numpy(), ocls), (K, bits, reverse, addc, clip)
+            cls2, none = eng.predict(batch, reverse, want_scores=False)
+            assert none is None and np.array_equal(cls2.cpu().numpy(), ocls)
+    eng.set_vw_options()
+
+
+@pytest.mark.parametrize("pattern,k", [("patterns_k64_t16_m4_s7.txt", 64), ("patterns_k64_t16_m8_s7.txt", 64),
+                                       ("patterns_k32_t8_m2_s11.txt", 32), ("patterns_hand_k16_t4_p11.txt", 16),
+                                       (None, 20)])
+def test_predict_other_geometries_and_long_reads(amd, eng, oracle, golden_dir, pattern, k):
+    rng = np.random.default_rng(11)
+    pos = _patterns(amd, golden_dir, pattern, k)
+    eng.set_patterns(pos, k)
+    seqs = _rand_seqs(rng, 9, 200) + [bytes(rng.choice(ACGT, size=L)) for L in (5000, 1537, 449, 450, 451, 3000)]
+    seqs[-1] = seqs[-1].lower()  # long raw read
+    K, bits = 356, 18
+    w = (rng.standard_normal(1 << bits) * 0.05).astype(np.float32)
+    eng.load_weights(w, K, bits)
+    batch = eng.upload(amd.PackedReads.from_sequences(seqs))
+    cls, sc = eng.predict(batch, True, want_scores=True)
+    ocls, osc, _ = oracle.predict(seqs, k, pos, True, w, K, bits)
+    assert np.array_equal(sc.cpu().numpy(), osc)
+    assert np.array_equal(cls.cpu().numpy(), ocls)
+    idx, off = eng.features(batch, True, 31)
+    oidx, ooff = oracle.features_batch(seqs, k, pos, True, 31)
+    assert np.array_equal(off.cpu().numpy().view(np.uint64), ooff)
+    assert np.array_equal(_u32(idx), oidx)
+
+
+def test_tie_break_and_clip_saturation(amd, eng, oracle, golden_dir):
+    """All-equal scores: VW's strict '>' keeps the lowest class; saturating clip makes many ties."""
+    rng = np.random.default_rng(3)
+    pos = _patterns(amd, golden_dir, "patterns_k64_t16_m1_s7.txt", 64)
+    eng.set_patterns(pos, 64)
+    seqs = _rand_seqs(rng, 16, 200)
+    batch = eng.upload(amd.PackedReads.from_sequences(seqs))
+    K, bits = 356, 14
+    eng.load_weights(np.zeros(1 << bits, dtype=np.float32), K, bits)
+    cls, _ = eng.predict(batch, True)
+    assert cls.cpu().numpy().tolist() == [1] * 16
+    w = (rng.standard_normal(1 << bits) * 5.0).astype(np.float32)  # everything saturates at +-1
+    eng.load_weights(w, K, bits)
+    eng.set_vw_options()
+    cls, sc = eng.predict(batch, True, want_scores=True)
+    ocls, osc, _ = oracle.predict(seqs, 64, pos, True, w, K, bits)
+    assert np.array_equal(sc.cpu().numpy(), osc) and np.array_equal(cls.cpu().numpy(), ocls)
+    assert (np.abs(osc) == 1.0).mean() > 0.5
+
+
+def test_empty_batch_and_error_paths(amd, eng, golden_dir):
+    from opal_amd._lib import OpalError
+    pos = _patterns(amd, golden_dir, "patterns_k64_t16_m1_s7.txt", 64)
+    eng.set_patterns(pos, 64)
+    eng.load_weights(np.zeros(1 << 10, dtype=np.float32), 4, 10)
+    batch = eng.upload(amd.PackedReads.from_sequences([]))
+    cls, _ = eng.predict(batch, True)
+    assert cls.numel() == 0
+    idx, off = eng.features(batch, True, 31)
+    assert idx.numel() == 0 and off.cpu().numpy().tolist() == [0]
+    with pytest.raises(OpalError):
+        eng.set_patterns(np.array([[0, 1, 70, 3]], dtype=np.int32), 64)      # position >= k
+    with pytest.raises(OpalError):
+        eng.set_patterns(np.zeros((1, 5), dtype=np.int32), 64)               # k % t != 0 (fasta2skm.py:125)
+    e2 = amd.Engine(0)
+    with pytest.raises(OpalError):
+        e2.predict(batch, True)                                              # nothing configured
+    e2.close()
+
+
+# ------------------------------------------------------------------------------ full-size properties
+def test_properties_at_scale(amd, eng, oracle, golden_dir):
+    """Config-2-shaped batch (200 bp, k=64, t=16, numHash=1, -r, K=356): size-independent properties."""
+    rng = np.random.default_rng(2024)
+    n, L, K, bits = 200_000, 200, 356, 24
+    pos = _patterns(amd, golden_dir, "patterns_k64_t16_m1_s7.txt", 64)
+    eng.set_patterns(pos, 64)
+    codes = rng.integers(0, 4, size=(n, L), dtype=np.uint8)
+    pr = amd.PackedReads.from_codes(codes)
+    batch = eng.upload(pr)
+    # (a) emit: checksum of all indices against the multi-threaded oracle, and exact offsets
+    blob = ACGT[codes].reshape(-1)
+    soff = (np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
+    idx, off = eng.features(batch, True, 31)
+    oidx, ooff = oracle.features_batch((blob, soff), 64, pos, True, 31, nthreads=0)
+    assert np.array_equal(off.cpu().numpy().view(np.uint64), ooff)
+    gi = _u32(idx)
+    assert int(gi.astype(np.uint64).sum()) == int(oidx.astype(np.uint64).sum())
+    assert np.array_equal(gi, oidx)
+    # (b) reverse-complement symmetry of the feature multiset: features(rc(x)) = [second half | first half] of features(x)
+    rc = (3 - codes[:, ::-1]).astype(np.uint8)
+    idx_rc, _ = eng.features(eng.upload(amd.PackedReads.from_codes(np.ascontiguousarray(rc))), True, 31)
+    F = 2 * (L - 64 + 1) * pos.shape[0]
+    a = gi.reshape(n, F)
+    b = _u32(idx_rc).reshape(n, F)
+    assert np.array_equal(b[:, :F // 2], a[:, F // 2:]) and np.array_equal(b[:, F // 2:], a[:, :F // 2])
+    # (c) predict: sharding invariance (any split of the batch gives the same per-fragment answers) ...
+    w = (rng.standard_normal(1 << bits) * 0.05).astype(np.float32)
+    eng.load_weights(w, K, bits)
+    eng.set_vw_options(clip=False)
+    cls, sc = eng.predict(batch, True, want_scores=True)
+    cut = 77_777
+    b1 = eng.upload(amd.PackedReads.from_codes(codes[:cut]))
+    b2 = eng.upload(amd.PackedReads.from_codes(codes[cut:]))
+    c1, s1 = eng.predict(b1, True, want_scores=True)
+    c2, s2 = eng.predict(b2, True, want_scores=True)
+    assert np.array_equal(np.concatenate([c1.cpu().numpy(), c2.cpu().numpy()]), cls.cpu().numpy())
+    assert np.array_equal(np.concatenate([s1.cpu().numpy(), s2.cpu().numpy()]), sc.cpu().numpy())
+    # ... exact scaling by a power of two, and agreement with the oracle on a bounded sample
+    eng.load_weights(w * np.float32(4.0), K, bits)
+    cls4, sc4 = eng.predict(batch, True, want_scores=True)
+    assert np.array_equal(sc4.cpu().numpy(), sc.cpu().numpy() * np.float32(4.0))
+    assert np.array_equal(cls4.cpu().numpy(), cls.cpu().numpy())
+    m = 4000
+    ocls, osc, _ = oracle.predict((blob[:m * L + 1], soff[:m + 1]), 64, pos, True, w, K, bits, clip=False, nthreads=0)
+    assert np.array_equal(sc.cpu().numpy()[:m], osc) and np.array_equal(cls.cpu().numpy()[:m], ocls)
+    eng.set_vw_options()
