@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Benchmark of the Opal hot path on MI355X: fused fragment -> LDPC spaced-k-mer hashes -> OAA scores -> class.
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the fused predict kernel over one batch of synthetic fragments that is already resident in
+HBM.  Default workload = BASELINE.json configs[1]: 356 classes, 1M fragments of 200 bp, k=64, row_weight=16,
+numHash=1, both strands (-r), 2^31-slot weight table.  Fragments shard across ranks with no collective
+(SURVEY.md §8e): every rank scores its own batch against its own replica of the table ("weak" scaling).
+
+Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes per launch / mean launch time measured with
+HIP events on the launch stream; `cpu_baseline` = the CPU oracle (oracle/, a bit-exact C port) timed on this
+box's host cores on a bounded sample of the same batch (rank 0, N=1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+WORKLOADS = {
+    # name: (K, n_frag per GPU, numHash pattern file, bits, mode)
+    "cfg1_toy10": dict(K=10, n=10_000, pattern="patterns_k64_t16_m1_s7.txt", bits=18, mode="predict",
+                       desc="10 classes, 1e4 x 200bp, numHash=1, b=18 (plumbing)"),
+    "cfg2_356sp_1M": dict(K=356, n=1_000_000, pattern="patterns_k64_t16_m1_s7.txt", bits=31, mode="predict",
+                          desc="356 classes, 1M x 200bp fragments, k=64 t=16 numHash=1, -r, b=31"),
+    "cfg3_1564sp": dict(K=1564, n=500_000, pattern="patterns_k64_t16_m1_s7.txt", bits=31, mode="predict",
+                        desc="1564 classes, 200bp fragments per GPU shard, numHash=1, -r, b=31"),
+    "cfg4_numhash4": dict(K=1564, n=200_000, pattern="patterns_k64_t16_m4_s7.txt", bits=31, mode="predict",
+                          desc="1564 classes, numHash=4 (P=5, F=1370), -r, b=31"),
+    "cfg5_emit": dict(K=0, n=4_000_000, pattern="patterns_k64_t16_m1_s7.txt", bits=31, mode="emit",
+                      desc="training-feature generation: emit hashed features of 200bp fragments, numHash=1, -r"),
+}
+
+
+def make_fragments(rank, n, L, K):
+    """Synthetic genomes (uniform ACGT, PCG64 seed 1234) sampled with the CPython-exact sampler (seed 42+rank)
+    through the C-ABI, like `opal.py frag` would (reference opal.py:187-196)."""
+    import opal_amd
+    n_genomes = max(K, 8)
+    glen = 1_000_000   # low coverage (a metagenomic sample covers its genomes thinly): rows are not re-used
+    g = np.random.Generator(np.random.PCG64(1234)).integers(0, 4, size=(n_genomes, glen), dtype=np.uint8)
+    cov = (n * L) / float(n_genomes * glen) * 1.02 + 1e-4
+    rng = opal_amd.Rng(42 + rank)
+    pos, gen = rng.sample_positions([glen] * n_genomes, L, cov)
+    assert len(pos) >= n, (len(pos), n)
+    # reads arrive in no particular order: shuffle with the same stream (as opal.py:363 does for training batches)
+    sel = rng.shuffle_perm(len(pos))[:n].astype(np.int64)
+    pos, gen = pos[sel].astype(np.int64), gen[sel].astype(np.int64)
+    codes = np.empty((n, L), dtype=np.uint8)
+    step = 100_000
+    ar = np.arange(L, dtype=np.int64)
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        codes[s:e] = g[gen[s:e, None], pos[s:e, None] + ar[None, :]]
+    return codes
+
+
+def algorithmic_bytes_per_fragment(L, F, K, mode):
+    if mode == "emit":
+        return math.ceil(L / 4) + 4 * F                      # 2-bit read + one u32 per feature
+    return math.ceil(L / 4) + 4 * K * (F + 1) + 4             # 2-bit read + (F+1) rows of K floats + class id
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg2_356sp_1M", choices=sorted(WORKLOADS))
+    ap.add_argument("--nfrag", type=int, default=0, help="override fragments per GPU")
+    ap.add_argument("--bits", type=int, default=0, help="override table bits")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=300_000)
+    args = ap.parse_args()
+
+    import torch
+    import opal_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.nfrag:
+        wl["n"] = args.nfrag
+    if args.bits:
+        wl["bits"] = args.bits
+    K, n, bits, mode = wl["K"], wl["n"], wl["bits"], wl["mode"]
+    L, k = 200, 64
+    with open(os.path.join(ROOT, "tests", "golden", wl["pattern"])) as f:
+        pos = opal_amd.parse_patterns(f.readlines(), k)
+    P = pos.shape[0]
+    F = (L - k + 1) * P * 2
+
+    dev = torch.device("cuda", local_rank)
+    eng = opal_amd.Engine(local_rank)
+    eng.set_patterns(pos, k)
+    w = None
+    if mode == "predict":
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(99)
+        w = torch.empty(1 << bits, dtype=torch.float32, device=dev)
+        w.normal_(0.0, 0.05, generator=gen)           # fp32 N(0, 0.05^2) dense table, same on every rank
+        eng.load_weights(w, K, bits)
+        eng.set_vw_options()                            # VW defaults: --hash strings, constant feature, clip to [-1,1]
+    codes = make_fragments(rank, n, L, max(K, 1))
+    batch = eng.upload(opal_amd.PackedReads.from_codes(codes))
+    out_class = torch.empty(n, dtype=torch.int32, device=dev)
+    if mode == "emit":
+        offsets = eng.feature_offsets(batch, True)
+        total = int(offsets[-1].item())
+        out_idx = torch.empty(total, dtype=torch.int32, device=dev)
+        from opal_amd._lib import check, lib
+
+        def step():
+            check(lib().opal_features(eng._h, batch.data.data_ptr(), batch.nbytes, batch.off.data_ptr(), batch.len.data_ptr(),
+                                      batch.n, 1, bits, offsets.data_ptr(), out_idx.data_ptr()), eng._h)
+    else:
+        def step():
+            eng.predict(batch, True, want_scores=False, out_class=out_class)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()      # torch's current stream IS the ctx stream (Engine binds to it), so these bracket the kernel
+        step()
+        b.record()
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    if rank == 0:
+        frag_per_s = world * n * args.steps / elapsed
+        abytes = algorithmic_bytes_per_fragment(L, F, K, mode) * n
+        achieved = abytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            with open(tp) as f:
+                traffic = json.load(f).get(args.workload if not (args.nfrag or args.bits) else "", {}).get("hbm_bytes_per_launch")
+        res = {
+            "metric": "fragments/sec", "value": frag_per_s, "unit": "fragments/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if mode == "predict" else "u32", "data": "synthetic",
+            "config": {"workload": args.workload, "desc": wl["desc"], "classes": K, "fragments_per_gpu": n, "frag_len": L,
+                       "kmer": k, "row_weight": 16, "patterns": P, "reverse_complement": True, "bits": bits,
+                       "features_per_fragment": F, "parallelism": "fragment-sharded x%d, replicated table, no collective" % world},
+            "hashes_per_s": frag_per_s * F,
+            "kernel": eng.predict_kernel_name() if mode == "predict" else "emit_idx_kernel",
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": abytes, "kernel_ms": kern_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(codes, pos, k, w, K, bits, mode, min(args.cpu_sample, n), out_class, eng, batch)
+        print(json.dumps(res), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(codes, pos, k, w, K, bits, mode, m, out_class, eng, batch):
+    """Times the CPU oracle (the checker, a scalar C port with OpenMP over fragments) on the first m fragments."""
+    from oracle import oracle as orc
+    orc.build()
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    L = codes.shape[1]
+    blob = np.ascontiguousarray(acgt[codes[:m]].reshape(-1))
+    blob = np.concatenate([blob, np.zeros(1, dtype=np.uint8)])
+    soff = np.arange(m + 1, dtype=np.uint64) * np.uint64(L)
+    threads = min(16, orc.max_threads())
+    if mode == "emit":
+        t0 = time.perf_counter()
+        idx, off = orc.features_batch((blob, soff), k, pos, True, bits, nthreads=threads)
+        dt = time.perf_counter() - t0
+        ok = None
+    else:
+        wh = w.cpu().numpy()
+        t0 = time.perf_counter()
+        cls, _, _ = orc.predict((blob, soff), k, pos, True, wh, K, bits, want_scores=False, nthreads=threads)
+        dt = time.perf_counter() - t0
+        ok = bool(np.array_equal(cls, out_class[:m].cpu().numpy()))   # the timed GPU output agrees with the checker
+        m1 = max(1000, m // 50)
+        t1 = time.perf_counter()
+        orc.predict((blob[:m1 * L + 1], soff[:m1 + 1]), k, pos, True, wh, K, bits, want_scores=False, nthreads=1)
+        dt1 = time.perf_counter() - t1
+    out = {"value": m / dt, "unit": "fragments/s", "cores": threads, "kind": "port",
+           "sample": "first %d fragments of the same batch, oracle/opal_oracle.c with %d OpenMP threads (%.1f s)" % (m, threads, dt)}
+    if mode != "emit":
+        out["value_1thread"] = m1 / dt1
+        out["gpu_matches_oracle_on_sample"] = ok
+        out["reference_python_1core"] = "3833 frag/s feature half only (BASELINE.md, survey container); vw absent"
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Condenses a scripts/profile.sh output directory into the few numbers DESIGN.md / bench.py quote.
+
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950
+FETCH_SIZE reports half of the bytes of a wide (16 B/lane) coalesced read, so the read side is doubled for the
+float4 row gathers; WRITE_SIZE is exact.  One --pmc pass per counter.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def rows(pattern):
+    for p in glob.glob(pattern, recursive=True):
+        with open(p, newline="") as f:
+            for r in csv.DictReader(f):
+                yield r
+
+
+def main(out):
+    res = {}
+    stats = {}
+    for r in rows(os.path.join(out, "kt", "**", "*kernel_stats.csv")):
+        stats[r["Name"]] = r
+    print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+    for name, r in sorted(stats.items(), key=lambda kv: -float(kv[1]["TotalDurationNs"])):
+        print("%-90s calls %5s  avg %12.1f us  total %10.3f ms  %5s%%" % (
+            name[:90], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
+    hot = [n for n in stats if "predict_kernel" in n or "emit_idx_kernel" in n]
+    if hot:
+        res["kernel"] = hot[0]
+        res["avg_kernel_ms"] = float(stats[hot[0]]["AverageNs"]) / 1e6
+        res["calls"] = int(stats[hot[0]]["Calls"])
+    for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+        vals = []
+        for r in rows(os.path.join(out, sub, "**", "*counter_collection.csv")):
+            if r.get("Counter_Name") == ctr and ("predict_kernel" in r["Kernel_Name"] or "emit_idx_kernel" in r["Kernel_Name"]):
+                vals.append(float(r["Counter_Value"]))
+        if vals:
+            res[ctr + "_KiB_per_launch"] = sum(vals) / len(vals)
+            res[ctr + "_launches"] = len(vals)
+    if "FETCH_SIZE_KiB_per_launch" in res:
+        rd = res["FETCH_SIZE_KiB_per_launch"] * 1024 * 2   # gfx950: wide coalesced reads are tallied at half
+        wr = res.get("WRITE_SIZE_KiB_per_launch", 0.0) * 1024
+        res["hbm_bytes_per_launch"] = rd + wr
+        res["hbm_read_bytes_per_launch_corrected_x2"] = rd
+        res["hbm_write_bytes_per_launch"] = wr
+    print("== summary ==")
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
