@@ -1,0 +1,75 @@
+"""Mirror of the reference's util/drawfrag.py: from each FASTA record draw random substrings of size l covering it
+c times (util/drawfrag.py:15-49).  Same argv, same output files, same CPython `random` stream: the positions come
+from libopal_hip.so's CPython-exact MT19937 (opal_sample_positions / opal_rng_randbelow).
+"""
+import argparse
+import sys
+
+from .engine import Rng
+from .fasta_functions import check_acgt, fasta_reader
+
+__version__ = "0.0.2"
+__all__ = ["main", "main_not_commandline", "sample_fragments"]
+
+
+def sample_fragments(records, taxid_lines, size, coverage, seed, atgc=False):
+    """records: [(name, seq)] str; taxid_lines: one label per record (missing -> '').  Returns
+    (fragments [str], labels [(firstname, taxid)]) in the reference's order."""
+    rng = Rng()
+    if seed:                                   # drawfrag.py:23-24: seed 0/None leaves the stream unseeded
+        rng.seed(seed)
+    frags, labels = [], []
+    if not atgc:
+        pos, gen = rng.sample_positions([len(s) for _, s in records], size, coverage)
+        for p, g in zip(pos.tolist(), gen.tolist()):
+            name, seq = records[g]
+            frags.append(seq[p:p + size])
+            labels.append((name.split()[0], taxid_lines[g] if g < len(taxid_lines) else ""))
+        return frags, labels
+    # --atgc (never enabled by opal.py): rejected draws still consume the stream (drawfrag.py:36-49)
+    for g, (name, seq) in enumerate(records):
+        if len(seq) < size:
+            continue
+        cov, tries, want = 0, 0, coverage * len(seq)
+        while cov < want:
+            tries += 1
+            p = rng.randint(0, len(seq) - size)
+            sample = seq[p:p + size]
+            if check_acgt(sample):
+                cov += size
+                frags.append(sample)
+                labels.append((name.split()[0], taxid_lines[g] if g < len(taxid_lines) else ""))
+            if tries > 10 * len(seq):
+                break
+    return frags, labels
+
+
+def main_not_commandline(args):
+    with open(args.input, "r", encoding="latin-1") as f:
+        records = list(fasta_reader(f))
+    with open(args.taxids, "r") as f:
+        taxid_lines = [l.rstrip("\n") for l in f]
+    frags, labels = sample_fragments(records, taxid_lines, args.size, args.coverage, args.seed, args.atgc)
+    with open(args.output, "w", encoding="latin-1") as out, open(args.gi2taxid, "w", encoding="latin-1") as g2t:
+        out.write("".join(">%d\n%s\n" % (i + 1, s) for i, s in enumerate(frags)))
+        g2t.write("".join("%s\t%s\n" % nl for nl in labels))
+
+
+def main(argv):
+    parser = argparse.ArgumentParser(formatter_class=argparse.RawTextHelpFormatter, description=__doc__)
+    parser.add_argument('--version', action='version', version='%(prog)s {version}'.format(version=__version__))
+    parser.add_argument('-i', '--input', help='file containing input sequences (fasta or fastq) [required]')
+    parser.add_argument('-l', '--size', help='size of drawn items [required]', type=int)
+    parser.add_argument('-t', '--taxids', help='one-column file containing the taxid of each input sequence [required]')
+    parser.add_argument('-c', '--coverage', help='mean coverage value for drawing fragments [required]', type=float)
+    parser.add_argument('-g', '--gi2taxid', help='output gi2taxids file: genome ids and taxids of the drawn fragments [required]')
+    parser.add_argument('-s', '--seed', help='random seed (reproducibility); unset/0 -> unseeded', type=int)
+    parser.add_argument('-o', '--output', help='output sequence file [required]')
+    parser.add_argument('--atgc', help='draw fragments made of ATCG only', action='store_true')
+    args = parser.parse_args(argv)
+    print(args)
+    main_not_commandline(args)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
