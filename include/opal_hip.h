@@ -123,6 +123,31 @@ int opal_feature_names(opal_ctx *ctx, const uint8_t *d_reads, uint64_t reads_byt
 int opal_predict(opal_ctx *ctx, const uint8_t *d_reads, uint64_t reads_bytes, const uint64_t *d_frag_off,
                  const uint32_t *d_frag_len, uint64_t n, int reverse, int32_t *d_out_class, float *d_out_scores);
 
+/* ---- trainer (replaces the `vw --oaa K --bit_precision b --l1 --l2 --save_resume` learner process that
+ * opal.py:307-327 starts and opal.py:363-367 feeds).  VW-like rule (adaptive AdaGrad
+ * accumulators + importance-invariant squared-loss step, labels +1/-1 per class), not VW's exact arithmetic:
+ * see opal_amd/csrc/opal_train.hip.  [VW-unpinned]                                                          */
+
+/* Allocates (resume=0: zeroed) the 2^bits weight table and its AdaGrad accumulators.  resume=1 keeps the weights
+ * already loaded in the ctx (same K and bits), like continuing from a --save_resume model.                   */
+int opal_train_begin(opal_ctx *ctx, int K, int bits, int resume);
+
+/* One pass over a batch of labelled fragments, in the order given (the caller shuffles: opal.py:363).
+ * d_labels[i] = VW class id (1..K) of fragment i (the "<label> |" prefix of the line, util/fasta2skm.py:82).
+ * eta: learning rate (vw -l, default 0.5); l1/l2: opal.py --lambda1/--lambda2.  sequential=1 runs the examples
+ * one after the other on a single wave (deterministic, slow: tests); 0 runs them concurrently (Hogwild).
+ * d_out_pred (optional): the class predicted for each example BEFORE its update (progressive validation).   */
+int opal_train_batch(opal_ctx *ctx, const uint8_t *d_reads, uint64_t reads_bytes, const uint64_t *d_frag_off,
+                     const uint32_t *d_frag_len, const int32_t *d_labels, uint64_t n, int reverse, float eta, float l1,
+                     float l2, int sequential, int32_t *d_out_pred);
+
+/* Copies the 2^bits compact weight table out of the ctx (dst on the device if dst_is_device, else on the host):
+ * what `vw -f model` would persist (opal.py:309).  Synchronises the stream.                                   */
+int opal_get_weights(opal_ctx *ctx, float *dst, int dst_is_device);
+
+/* Loads a model stored as nnz (slot index, weight) pairs (host arrays); all other slots are 0.                */
+int opal_load_weights_sparse(opal_ctx *ctx, const uint32_t *idx, const float *val, uint64_t nnz, int K, int bits);
+
 /* Name of the scoring-kernel variant opal_predict would launch for the current K (for profiles/bench).   */
 const char *opal_predict_kernel_name(opal_ctx *ctx);
 

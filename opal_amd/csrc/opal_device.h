@@ -1,0 +1,258 @@
+// Device code shared by every kernel of libopal_hip.so: fragment staging, MurmurHash3, the fragment walker
+// (phase H) and the pipelined weight-row stream (phase S).  Included by opal_kernels.hip and opal_train.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "opal_hip.h"
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int WPB = 4;          // waves per block
+constexpr int BLOCK = WAVE * WPB;
+constexpr int SEQB = 512;       // bytes of one strand tile held in LDS per wave
+constexpr int HB = 1536;        // hash-buffer entries (u32) per wave
+constexpr int HB_PAD = 16;      // dummy entries after the live ones (prefetch overrun target)
+
+struct Batch {
+    const uint8_t *reads;
+    uint64_t reads_bytes;
+    const uint64_t *off;
+    const uint32_t *len;
+    uint64_t n;
+};
+struct Geom {
+    const uint8_t *pos;  // P*t
+    int k, P, t;
+    int reverse;
+    int hash_all;
+};
+
+// ------------------------------------------------------------------------------------------ byte helpers
+__device__ __forceinline__ uint32_t rc_byte(uint32_t c)
+{
+    // str.translate(maketrans('ATGCatgc','TACGTACG')): util/fasta_functions.py:46-50
+    const uint32_t u = c | 0x20u;
+    uint32_t r = c;
+    r = (u == 'a') ? 'T' : r;
+    r = (u == 't') ? 'A' : r;
+    r = (u == 'g') ? 'C' : r;
+    r = (u == 'c') ? 'G' : r;
+    return r;
+}
+
+// Loads bytes [i0, i0+cnt) of strand `strand` of one fragment into LDS as the ASCII text the reference sees.
+__device__ __forceinline__ void load_tile(uint8_t *sq, const uint8_t *src, uint32_t len, bool raw, int strand,
+                                          uint32_t i0, uint32_t cnt, int lane)
+{
+    for (uint32_t i = lane; i < cnt; i += WAVE) {
+        const uint32_t p = i0 + i;
+        const uint32_t sp = strand ? (len - 1u - p) : p;
+        uint32_t c;
+        if (raw) {
+            c = src[sp];
+        } else {
+            const uint32_t code = (src[sp >> 2] >> ((sp & 3u) * 2u)) & 3u;
+            c = (0x54474341u >> (code * 8u)) & 0xffu;  // "ACGT"
+        }
+        if (strand) c = rc_byte(c);
+        sq[i] = (uint8_t)c;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ MurmurHash3_x86_32
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return __builtin_rotateleft32(x, r); }
+__device__ __forceinline__ uint32_t mm_k(uint32_t k1)
+{
+    k1 *= 0xcc9e2d51u;
+    k1 = rotl32(k1, 15);
+    k1 *= 0x1b873593u;
+    return k1;
+}
+__device__ __forceinline__ uint32_t mm_h(uint32_t h, uint32_t k1)
+{
+    h ^= mm_k(k1);
+    h = rotl32(h, 13);
+    return h * 5u + 0xe6546b64u;
+}
+__device__ __forceinline__ uint32_t mm_fin(uint32_t h, uint32_t len)
+{
+    h ^= len;
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
+
+// Hash of the feature name "<t gathered chars><decimal p>" (util/fasta2skm.py:140) for window base `wb`
+// (LDS pointer to the window's first byte).  T > 0: t known at compile time (fully unrolled), p < 10.
+template <int T>
+__device__ __forceinline__ uint32_t hash_name_fast(const uint8_t *wb, const uint8_t *__restrict__ pp, int p)
+{
+    static_assert(T % 4 == 0, "fast path needs whole blocks");
+    uint32_t h = 0;
+    // pp is wave-uniform and 4-byte aligned (T % 4 == 0, table base from hipMalloc): one scalar dword per block
+    const uint32_t *__restrict__ pw = reinterpret_cast<const uint32_t *>(pp);
+#pragma unroll
+    for (int b = 0; b < T / 4; b++) {
+        const uint32_t q = pw[b];
+        const uint32_t k1 = (uint32_t)wb[q & 0xffu] | ((uint32_t)wb[(q >> 8) & 0xffu] << 8) |
+                            ((uint32_t)wb[(q >> 16) & 0xffu] << 16) | ((uint32_t)wb[q >> 24] << 24);
+        h = mm_h(h, k1);
+    }
+    h ^= mm_k((uint32_t)('0' + p));
+    return mm_fin(h, T + 1);
+}
+
+// Generic: any t, any p < 1000, optional VW `--hash strings` digit rule (all-digit names are numbers).
+__device__ __forceinline__ uint32_t hash_name_generic(const uint8_t *wb, const uint8_t *__restrict__ pp, int t, int p,
+                                                      bool digit_rule, uint32_t mask)
+{
+    uint32_t h = 0, k1 = 0;
+    uint32_t n = 0;
+    bool digits = true;
+    uint64_t num = 0;
+    auto feed = [&](uint32_t c) {
+        k1 |= c << (8u * (n & 3u));
+        n++;
+        if ((n & 3u) == 0) { h = mm_h(h, k1); k1 = 0; }
+        const uint32_t d = c - (uint32_t)'0';
+        digits = digits && (d <= 9u);
+        num = num * 10ull + d;
+    };
+    for (int j = 0; j < t; j++) feed(wb[pp[j]]);
+    if (p >= 100) feed('0' + (p / 100) % 10);
+    if (p >= 10) feed('0' + (p / 10) % 10);
+    feed('0' + p % 10);
+    if (n & 3u) h ^= mm_k(k1);
+    h = mm_fin(h, n);
+    if (digit_rule && digits) return (uint32_t)num & mask;  // hashstring(): ret + seed with seed 0  [VW-unpinned]
+    return h & mask;
+}
+
+// ------------------------------------------------------------------------------------------ phase H
+// Walks one fragment, appending masked hashes to the LDS buffer hb; calls flush(count) whenever the buffer
+// is full and once at the end (after the optional constant feature).  flush must consume hb[0..count).
+template <class Flush>
+__device__ __forceinline__ void walk_fragment(const Batch &B, const Geom &G, uint64_t frag, uint32_t mask,
+                                              bool add_const, uint32_t const_idx, uint8_t *sq, uint32_t *hb, int lane,
+                                              Flush &&flush)
+{
+    const uint32_t lw = B.len[frag];
+    const bool raw = (lw & OPAL_RAW_FLAG) != 0;
+    uint32_t len = lw & ~OPAL_RAW_FLAG;
+    const uint64_t off = B.off[frag];
+    const uint64_t nbytes = raw ? (uint64_t)len : ((uint64_t)len + 3) / 4;
+    if (off > B.reads_bytes || nbytes > B.reads_bytes - off) len = 0;  // never read outside the batch buffer
+    const uint8_t *src = B.reads + off;
+    const int k = G.k, P = G.P, t = G.t;
+    const bool fast16 = (t == 16) && (P <= 10) && !raw;
+    const bool digit_rule = raw && !G.hash_all;
+    uint32_t fill = 0;
+    if (len >= (uint32_t)k) {
+        const uint32_t W = len - (uint32_t)k + 1u;
+        const uint32_t tw_seq = (uint32_t)(SEQB - k + 1);
+        for (int s = 0; s < (G.reverse ? 2 : 1); s++) {
+            uint32_t w0 = 0;
+            while (w0 < W) {
+                uint32_t room = (HB - fill) / (uint32_t)P;
+                if (room < min(W - w0, (uint32_t)WAVE)) { flush(fill); fill = 0; room = HB / (uint32_t)P; }
+                const uint32_t tw = min(min(W - w0, tw_seq), room);
+                load_tile(sq, src, len, raw, s, w0, tw + (uint32_t)k - 1u, lane);
+                // wave-private LDS: every lane's ds_write retires before the next ds_read issues (same wave,
+                // in-order LDS queue); the fence only stops the compiler from reordering.
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int p = 0; p < P; p++) {
+                    const uint8_t *pp = G.pos + p * t;
+                    for (uint32_t wl = lane; wl < tw; wl += WAVE) {
+                        uint32_t h;
+                        if (fast16) h = hash_name_fast<16>(sq + wl, pp, p) & mask;
+                        else h = hash_name_generic(sq + wl, pp, t, p, digit_rule, mask);
+                        hb[fill + wl * (uint32_t)P + (uint32_t)p] = h;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                fill += tw * (uint32_t)P;
+                w0 += tw;
+            }
+        }
+    }
+    if (add_const) {
+        if (fill == HB) { flush(fill); fill = 0; }
+        if (lane == 0) hb[fill] = const_idx;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        fill++;
+    }
+    flush(fill);
+}
+
+// ------------------------------------------------------------------------------------------ phase S
+template <int VEC> struct VecOf;
+template <> struct VecOf<1> { using type = float; };
+template <> struct VecOf<2> { using type = float2; };
+template <> struct VecOf<4> { using type = float4; };
+
+template <int VEC> __device__ __forceinline__ float vget(const typename VecOf<VEC>::type &v, int e);
+template <> __device__ __forceinline__ float vget<1>(const float &v, int) { return v; }
+template <> __device__ __forceinline__ float vget<2>(const float2 &v, int e) { return e ? v.y : v.x; }
+template <> __device__ __forceinline__ float vget<4>(const float4 &v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+
+__device__ __forceinline__ void vadd(float &a, const float &b) { a += b; }
+__device__ __forceinline__ void vadd(float2 &a, const float2 &b) { a.x += b.x; a.y += b.y; }
+__device__ __forceinline__ void vadd(float4 &a, const float4 &b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+
+// Streams rows hb[0..nf) of the padded weight table into acc.  hb[nf .. nf+U) must be readable (dummy rows:
+// they are loaded and never consumed).  loff[j] = this lane's float offset inside a row for vector j (already
+// clamped into the row, so every load is unconditional).
+template <int VEC, int NV, int U, bool WRAP = false>
+__device__ __forceinline__ void stream_rows(const float *__restrict__ tab, const uint32_t *hb, uint32_t nf, uint32_t K,
+                                            uint32_t mask, const uint32_t (&loff)[NV],
+                                            typename VecOf<VEC>::type (&acc)[NV])
+{
+    using V = typename VecOf<VEC>::type;
+    V r[U][NV];
+    // WRAP=false: the table is padded with a mirror of its head, rows are contiguous (predict).
+    // WRAP=true : canonical slots only, every lane wraps its own address (trainer: the mirror may be stale).
+    auto row_of = [&](uint32_t f) -> uint32_t {
+        const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)hb[f]);
+        return (idx * K) & mask;  // (h*K) mod 2^b, b <= 32: low 32 bits suffice
+    };
+    auto ld = [&](uint32_t row, uint32_t lo) -> V {
+        if constexpr (WRAP) return *reinterpret_cast<const V *>(tab + (size_t)((row + lo) & mask));
+        else return *reinterpret_cast<const V *>(tab + (size_t)row + lo);
+    };
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const uint32_t row = row_of(u);
+#pragma unroll
+        for (int j = 0; j < NV; j++) r[u][j] = ld(row, loff[j]);
+    }
+    uint32_t f = 0;
+    for (; f + U <= nf; f += U) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t row = row_of(f + U + u);
+#pragma unroll
+            for (int j = 0; j < NV; j++) {
+                vadd(acc[j], r[u][j]);
+                r[u][j] = ld(row, loff[j]);
+            }
+        }
+    }
+    const uint32_t rem = nf - f;  // < U, wave-uniform
+#pragma unroll
+    for (int u = 0; u < U - 1; u++) {
+        if ((uint32_t)u < rem) {
+#pragma unroll
+            for (int j = 0; j < NV; j++) vadd(acc[j], r[u][j]);
+        }
+    }
+}
+
+}  // namespace

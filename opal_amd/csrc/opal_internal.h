@@ -17,6 +17,9 @@ struct opal_ctx {
     // weights (VW regressor, compact `w` components)
     float *d_w = nullptr;      // 2^bits + pad floats: first K(+3) floats mirrored at the end so rows never wrap
     uint64_t w_alloc_floats = 0;
+    float *d_g2 = nullptr;     // trainer: AdaGrad accumulators, 2^bits floats (canonical slots only)
+    uint64_t g2_alloc_floats = 0;
+    bool g2_valid = false;
     uint64_t n_slots = 0;
     int K = 0, bits = 0;
     // VW switches

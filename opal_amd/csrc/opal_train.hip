@@ -1,0 +1,361 @@
+// Native one-against-all trainer: replaces the `vw --oaa K -b bits --save_resume` process that the reference
+// feeds at opal.py:307-327,363-367.  One wave owns one training example (= one fragment);
+// per example and class c (labels y_c = +1 for the example's class, -1 otherwise; squared loss; every feature
+// value is 1):
+//   sweep 1  p_c  = sum_f w[slot(f,c)]                     (phase S of the predict kernel, same order)
+//            err_c = y_c - clip(p_c, [min_label,max_label]);  s = eta / sqrt(#features)
+//   sweep 2  G[slot(f,c)] += 4 err_c^2;  ppu_c += 1/sqrt(G[slot(f,c)])        (AdaGrad accumulators, VW --adaptive)
+//            u_c = s*ppu_c < 1e-6 ? 2 err_c s : err_c (1 - exp(-2 s ppu_c)) / ppu_c   (VW --invariant, squared loss)
+//   sweep 3  w[slot(f,c)] += u_c / sqrt(G[slot(f,c)])      (then optional l2 decay / l1 soft-threshold)
+// slot(f,c) = (h_f*K + c) mod 2^b, features in the reference's order, the constant feature last.
+// This is a VW-like rule, not VW's exact one (VW is absent: parity unpinned); oracle/opal_oracle.c restates it
+// sequentially and tests compare the two in `sequential` mode (one wave, examples in order).
+// In the default mode all waves run concurrently (Hogwild): k-mer rows are updated with plain read-modify-write,
+// the constant row (shared by every example) with float atomics.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <string>
+
+#include "opal_device.h"
+#include "opal_internal.h"
+
+namespace {
+
+template <int VEC>
+__device__ __forceinline__ void vload(const float *p, float (&o)[VEC])
+{
+    if constexpr (VEC == 4) { const float4 v = *reinterpret_cast<const float4 *>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    else if constexpr (VEC == 2) { const float2 v = *reinterpret_cast<const float2 *>(p); o[0] = v.x; o[1] = v.y; }
+    else o[0] = *p;
+}
+template <int VEC>
+__device__ __forceinline__ void vstore(float *p, const float (&o)[VEC])
+{
+    if constexpr (VEC == 4) *reinterpret_cast<float4 *>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    else if constexpr (VEC == 2) *reinterpret_cast<float2 *>(p) = make_float2(o[0], o[1]);
+    else *p = o[0];
+}
+
+struct TrainArgs {
+    float eta, l1, l2, min_label, max_label;
+    int sequential;
+};
+
+template <int VEC, int NV, int U>
+__global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__restrict__ w, float *__restrict__ g2,
+                                                       uint32_t mask, int K, uint32_t const_idx,
+                                                       const int32_t *__restrict__ labels, TrainArgs ta,
+                                                       int32_t *__restrict__ out_pred)
+{
+    using V = typename VecOf<VEC>::type;
+    constexpr int CH = WAVE * VEC * NV;
+    __shared__ __attribute__((aligned(16))) uint8_t s_seq[WPB][SEQB];
+    __shared__ __attribute__((aligned(16))) uint32_t s_hb[WPB][HB + HB_PAD];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wv = threadIdx.x / WAVE;
+    uint32_t *hb = s_hb[wv];
+    uint64_t nwaves = (uint64_t)gridDim.x * WPB;
+    uint64_t first = (uint64_t)blockIdx.x * WPB + wv;
+    if (ta.sequential) {
+        if (first != 0) return;
+        nwaves = 1;
+    }
+    const uint32_t Ku = (uint32_t)K;
+
+    for (uint64_t frag = first; frag < B.n; frag += nwaves) {
+        const uint32_t label = (uint32_t)(labels[frag] - 1);   // VW class ids are 1-based
+        float best = 0.0f;
+        uint32_t best_c = 0xffffffffu;
+        for (uint32_t c0 = 0; c0 < Ku; c0 += CH) {
+            uint32_t loff[NV], cls[NV];
+#pragma unroll
+            for (int j = 0; j < NV; j++) {
+                cls[j] = c0 + (uint32_t)(j * WAVE + lane) * VEC;
+                loff[j] = min(cls[j], Ku - VEC);
+            }
+            // ---- sweep 1: scores (identical to predict)
+            V acc[NV];
+#pragma unroll
+            for (int j = 0; j < NV; j++) acc[j] = V{};
+            uint32_t nfeat = 0;
+            walk_fragment(B, G, frag, mask, true, const_idx, s_seq[wv], hb, lane, [&](uint32_t cnt) {
+                if (lane < HB_PAD) hb[cnt + lane] = const_idx;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                stream_rows<VEC, NV, U, true>(w, hb, cnt, Ku, mask, loff, acc);
+                nfeat += cnt;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            });
+            float err[NV][VEC], gsq[NV][VEC], ppu[NV][VEC], upd[NV][VEC];
+#pragma unroll
+            for (int j = 0; j < NV; j++)
+#pragma unroll
+                for (int e = 0; e < VEC; e++) {
+                    float p = vget<VEC>(acc[j], e);
+                    if (p != p) p = 0.0f;
+                    else if (p > ta.max_label) p = ta.max_label;
+                    else if (p < ta.min_label) p = ta.min_label;
+                    const uint32_t c = cls[j] + e;
+                    if (cls[j] < Ku && (best_c == 0xffffffffu || p > best)) { best = p; best_c = c; }
+                    const float y = (c == label) ? 1.0f : -1.0f;
+                    err[j][e] = y - p;
+                    gsq[j][e] = 4.0f * err[j][e] * err[j][e];
+                    ppu[j][e] = 0.0f;
+                }
+            const float s = ta.eta / sqrtf((float)nfeat);
+            // ---- sweep 2: adaptive accumulators + prediction-per-update
+            walk_fragment(B, G, frag, mask, true, const_idx, s_seq[wv], hb, lane, [&](uint32_t cnt) {
+                for (uint32_t f = 0; f < cnt; f++) {
+                    const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)hb[f]);
+                    const uint32_t row = (idx * Ku) & mask;
+                    const bool shared_row = (idx == const_idx) && !ta.sequential;
+#pragma unroll
+                    for (int j = 0; j < NV; j++) {
+                        if (cls[j] < Ku) {
+                            float *gp = g2 + (size_t)((row + cls[j]) & mask);
+                            float gv[VEC];
+                            if (shared_row) {   // every example touches the constant row: returning atomics, no lost adds
+#pragma unroll
+                                for (int e = 0; e < VEC; e++) gv[e] = atomicAdd(gp + e, gsq[j][e]) + gsq[j][e];
+                            } else {
+                                vload<VEC>(gp, gv);
+#pragma unroll
+                                for (int e = 0; e < VEC; e++) gv[e] += gsq[j][e];
+                                vstore<VEC>(gp, gv);
+                            }
+#pragma unroll
+                            for (int e = 0; e < VEC; e++) ppu[j][e] += (gv[e] > 0.0f) ? 1.0f / sqrtf(gv[e]) : 0.0f;
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            });
+#pragma unroll
+            for (int j = 0; j < NV; j++)
+#pragma unroll
+                for (int e = 0; e < VEC; e++) {
+                    const float x = s * ppu[j][e];
+                    float u;
+                    if (err[j][e] == 0.0f || ppu[j][e] == 0.0f) u = 0.0f;
+                    else if (x < 1e-6f) u = 2.0f * err[j][e] * s;
+                    else u = err[j][e] * (1.0f - expf(-2.0f * x)) / ppu[j][e];
+                    upd[j][e] = u;
+                }
+            // ---- sweep 3: weight update
+            const float decay = 1.0f - s * ta.l2;
+            const float shrink = s * ta.l1;
+            const bool reg = (ta.l1 != 0.0f) || (ta.l2 != 0.0f);
+            walk_fragment(B, G, frag, mask, true, const_idx, s_seq[wv], hb, lane, [&](uint32_t cnt) {
+                for (uint32_t f = 0; f < cnt; f++) {
+                    const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)hb[f]);
+                    const uint32_t row = (idx * Ku) & mask;
+                    const bool shared_row = (idx == const_idx) && !ta.sequential;
+#pragma unroll
+                    for (int j = 0; j < NV; j++) {
+                        if (cls[j] < Ku) {
+                            const size_t slot = (size_t)((row + cls[j]) & mask);
+                            float gv[VEC], d[VEC];
+                            vload<VEC>(g2 + slot, gv);
+#pragma unroll
+                            for (int e = 0; e < VEC; e++) d[e] = (gv[e] > 0.0f) ? upd[j][e] / sqrtf(gv[e]) : 0.0f;
+                            if (shared_row && !reg) {
+#pragma unroll
+                                for (int e = 0; e < VEC; e++) atomicAdd(w + slot + e, d[e]);
+                            } else {
+                                float wv4[VEC];
+                                vload<VEC>(w + slot, wv4);
+#pragma unroll
+                                for (int e = 0; e < VEC; e++) {
+                                    float nw = wv4[e] + d[e];
+                                    if (reg) {
+                                        nw *= decay;
+                                        nw = nw > shrink ? nw - shrink : (nw < -shrink ? nw + shrink : 0.0f);
+                                    }
+                                    wv4[e] = nw;
+                                }
+                                vstore<VEC>(w + slot, wv4);
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            });
+        }
+        if (out_pred) {
+#pragma unroll
+            for (int d = 1; d < WAVE; d <<= 1) {
+                const float ob = __shfl_xor(best, d, WAVE);
+                const uint32_t oc = (uint32_t)__shfl_xor((int)best_c, d, WAVE);
+                const bool take = (oc != 0xffffffffu) && (best_c == 0xffffffffu || ob > best || (ob == best && oc < best_c));
+                if (take) { best = ob; best_c = oc; }
+            }
+            if (lane == 0) out_pred[frag] = (int32_t)(best_c + 1u);
+        }
+    }
+}
+
+struct TVariant {
+    int vec, nv;
+    const void *fn;
+};
+#define OPAL_TV(VEC, NV, U) {VEC, NV, (const void *)&train_kernel<VEC, NV, U>}
+const TVariant kTrainVariants[] = {
+    OPAL_TV(1, 1, 8), OPAL_TV(1, 2, 8), OPAL_TV(1, 4, 4), OPAL_TV(1, 8, 2),
+    OPAL_TV(2, 1, 8), OPAL_TV(2, 2, 8), OPAL_TV(2, 4, 4), OPAL_TV(2, 8, 2),
+    OPAL_TV(4, 1, 8), OPAL_TV(4, 2, 8), OPAL_TV(4, 4, 4), OPAL_TV(4, 8, 2),
+};
+
+const TVariant &pick_train_variant(int K)
+{
+    const int vec = (K % 4 == 0) ? 4 : (K % 2 == 0) ? 2 : 1;
+    const int need = (K + WAVE * vec - 1) / (WAVE * vec);
+    const int nv = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 8;
+    for (const TVariant &v : kTrainVariants)
+        if (v.vec == vec && v.nv == nv) return v;
+    return kTrainVariants[0];
+}
+
+__global__ void mirror_head_kernel2(float *w, uint64_t n_slots, uint32_t pad)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < pad) w[n_slots + i] = w[i % n_slots];
+}
+
+__global__ void scatter_weights_kernel(float *__restrict__ w, const uint32_t *__restrict__ idx, const float *__restrict__ val,
+                                       uint64_t nnz, uint64_t n_slots)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += stride)
+        if (idx[i] < n_slots) w[idx[i]] = val[i];
+}
+
+int refresh_mirror(opal_ctx *ctx)
+{
+    const uint32_t pad = (uint32_t)ctx->K + 4;
+    hipLaunchKernelGGL(mirror_head_kernel2, dim3((pad + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_w, ctx->n_slots, pad);
+    OPAL_HIP_CHECK(ctx, hipGetLastError());
+    return OPAL_OK;
+}
+
+int alloc_floats(opal_ctx *ctx, float **p, uint64_t *cap, uint64_t need)
+{
+    if (*cap < need) {
+        if (*p) { OPAL_HIP_CHECK(ctx, hipFree(*p)); *p = nullptr; *cap = 0; }
+        hipError_t e = hipMalloc((void **)p, need * sizeof(float));
+        if (e != hipSuccess) return opal::fail(ctx, OPAL_ENOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+        *cap = need;
+    }
+    return OPAL_OK;
+}
+
+}  // namespace
+
+extern "C" int opal_train_begin(opal_ctx *ctx, int K, int bits, int resume)
+{
+    if (!ctx) return opal::fail(nullptr, OPAL_EINVAL, "opal_train_begin: null ctx");
+    if (bits < 1 || bits > 32) return opal::fail(ctx, OPAL_EINVAL, "opal_train_begin: need 1 <= bits <= 32");
+    if (K < 1 || K > (1 << 20)) return opal::fail(ctx, OPAL_EINVAL, "opal_train_begin: need 1 <= K <= 2^20");
+    OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    OPAL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t n_slots = 1ull << bits;
+    const uint64_t need = n_slots + (uint64_t)K + 4;
+    const bool keep = resume && ctx->d_w && ctx->K == K && ctx->bits == bits;
+    if (resume && !keep) return opal::fail(ctx, OPAL_ESTATE, "opal_train_begin: resume needs weights with the same K and bits loaded");
+    int rc = alloc_floats(ctx, &ctx->d_w, &ctx->w_alloc_floats, need);
+    if (rc) return rc;
+    rc = alloc_floats(ctx, &ctx->d_g2, &ctx->g2_alloc_floats, n_slots);
+    if (rc) return rc;
+    ctx->n_slots = n_slots; ctx->K = K; ctx->bits = bits;
+    if (!keep) {
+        OPAL_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_w, 0, need * sizeof(float), ctx->stream));
+        OPAL_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_g2, 0, n_slots * sizeof(float), ctx->stream));
+    } else if (!ctx->g2_valid) {
+        OPAL_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_g2, 0, n_slots * sizeof(float), ctx->stream));
+    }
+    ctx->g2_valid = true;
+    return OPAL_OK;
+}
+
+extern "C" int opal_train_batch(opal_ctx *ctx, const uint8_t *d_reads, uint64_t reads_bytes, const uint64_t *d_frag_off,
+                                const uint32_t *d_frag_len, const int32_t *d_labels, uint64_t n, int reverse, float eta,
+                                float l1, float l2, int sequential, int32_t *d_out_pred)
+{
+    if (!ctx) return opal::fail(nullptr, OPAL_EINVAL, "opal_train_batch: null ctx");
+    if (ctx->P == 0) return opal::fail(ctx, OPAL_ESTATE, "opal_train_batch: opal_set_patterns has not been called");
+    if (!ctx->d_w || !ctx->d_g2 || !ctx->g2_valid) return opal::fail(ctx, OPAL_ESTATE, "opal_train_batch: call opal_train_begin first");
+    if (n && (!d_reads || !d_frag_off || !d_frag_len || !d_labels)) return opal::fail(ctx, OPAL_EINVAL, "opal_train_batch: null batch pointer");
+    if (!(eta > 0.0f) || l1 < 0.0f || l2 < 0.0f) return opal::fail(ctx, OPAL_EINVAL, "opal_train_batch: need eta > 0, l1 >= 0, l2 >= 0");
+    if (n == 0) return OPAL_OK;
+    OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    Batch B{d_reads, reads_bytes, d_frag_off, d_frag_len, n};
+    Geom G{ctx->d_pos, ctx->k, ctx->P, ctx->t, reverse != 0, ctx->hash_all};
+    const uint32_t mask = ctx->bits == 32 ? 0xffffffffu : ((1u << ctx->bits) - 1u);
+    const uint32_t const_idx = OPAL_VW_CONSTANT & mask;
+    const TVariant &v = pick_train_variant(ctx->K);
+    int per_cu = 0;
+    OPAL_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v.fn, BLOCK, 0));
+    if (per_cu < 1) per_cu = 1;
+    const uint64_t want = (n + WPB - 1) / WPB;
+    int grid = sequential ? 1 : (int)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)ctx->num_cus * per_cu));
+    float *w = ctx->d_w, *g2 = ctx->d_g2;
+    int K = ctx->K;
+    TrainArgs ta{eta, l1, l2, ctx->min_label, ctx->max_label, sequential != 0};
+    void *args[] = {&B, &G, &w, &g2, (void *)&mask, &K, (void *)&const_idx, &d_labels, &ta, &d_out_pred};
+    OPAL_HIP_CHECK(ctx, hipLaunchKernel(v.fn, dim3(grid), dim3(BLOCK), args, 0, ctx->stream));
+    // keep the wrap padding coherent so that opal_predict can be called between batches
+    return refresh_mirror(ctx);
+}
+
+extern "C" int opal_get_weights(opal_ctx *ctx, float *dst, int dst_is_device)
+{
+    if (!ctx) return opal::fail(nullptr, OPAL_EINVAL, "opal_get_weights: null ctx");
+    if (!ctx->d_w || ctx->K == 0) return opal::fail(ctx, OPAL_ESTATE, "opal_get_weights: no weights");
+    if (!dst) return opal::fail(ctx, OPAL_EINVAL, "opal_get_weights: null dst");
+    OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    OPAL_HIP_CHECK(ctx, hipMemcpyAsync(dst, ctx->d_w, ctx->n_slots * sizeof(float),
+                                       dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    OPAL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return OPAL_OK;
+}
+
+extern "C" int opal_load_weights_sparse(opal_ctx *ctx, const uint32_t *idx, const float *val, uint64_t nnz, int K, int bits)
+{
+    if (!ctx) return opal::fail(nullptr, OPAL_EINVAL, "opal_load_weights_sparse: null ctx");
+    if (nnz && (!idx || !val)) return opal::fail(ctx, OPAL_EINVAL, "opal_load_weights_sparse: null arrays");
+    if (bits < 1 || bits > 32) return opal::fail(ctx, OPAL_EINVAL, "opal_load_weights_sparse: need 1 <= bits <= 32");
+    if (K < 1 || K > (1 << 20)) return opal::fail(ctx, OPAL_EINVAL, "opal_load_weights_sparse: need 1 <= K <= 2^20");
+    OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    OPAL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t n_slots = 1ull << bits;
+    const uint64_t need = n_slots + (uint64_t)K + 4;
+    int rc = alloc_floats(ctx, &ctx->d_w, &ctx->w_alloc_floats, need);
+    if (rc) return rc;
+    ctx->n_slots = n_slots; ctx->K = K; ctx->bits = bits; ctx->g2_valid = false;
+    OPAL_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_w, 0, need * sizeof(float), ctx->stream));
+    if (nnz) {
+        uint32_t *d_idx = nullptr;
+        float *d_val = nullptr;
+        OPAL_HIP_CHECK(ctx, hipMalloc((void **)&d_idx, nnz * sizeof(uint32_t)));
+        hipError_t e = hipMalloc((void **)&d_val, nnz * sizeof(float));
+        if (e != hipSuccess) { (void)hipFree(d_idx); return opal::fail(ctx, OPAL_ENOMEM, "opal_load_weights_sparse: hipMalloc failed"); }
+        e = hipMemcpyAsync(d_idx, idx, nnz * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_val, val, nnz * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            const int grid = (int)std::min<uint64_t>((nnz + 255) / 256, 65536);
+            hipLaunchKernelGGL(scatter_weights_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->d_w, d_idx, d_val, nnz, n_slots);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_idx);
+        (void)hipFree(d_val);
+        if (e != hipSuccess) return opal::fail(ctx, OPAL_EHIP, std::string("opal_load_weights_sparse: ") + hipGetErrorString(e));
+    }
+    rc = refresh_mirror(ctx);
+    if (rc) return rc;
+    OPAL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return OPAL_OK;
+}

@@ -12,10 +12,11 @@ __version__ = "0.0.2"
 __all__ = ["main", "main_not_commandline", "sample_fragments"]
 
 
-def sample_fragments(records, taxid_lines, size, coverage, seed, atgc=False):
+def sample_fragments(records, taxid_lines, size, coverage, seed, atgc=False, rng=None):
     """records: [(name, seq)] str; taxid_lines: one label per record (missing -> '').  Returns
-    (fragments [str], labels [(firstname, taxid)]) in the reference's order."""
-    rng = Rng()
+    (fragments [str], labels [(firstname, taxid)]) in the reference's order.  rng: an opal_amd.Rng to draw
+    from (the reference uses the process-wide `random`, which opal.py:363 keeps drawing from for its shuffle)."""
+    rng = rng or Rng()
     if seed:                                   # drawfrag.py:23-24: seed 0/None leaves the stream unseeded
         rng.seed(seed)
     frags, labels = [], []

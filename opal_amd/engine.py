@@ -229,3 +229,40 @@ class Engine:
         check(lib().opal_predict(self._h, b.data.data_ptr(), b.nbytes, b.off.data_ptr(), b.len.data_ptr(), b.n,
                                  int(reverse), out_class.data_ptr(), out_scores.data_ptr() if want_scores else None), self._h)
         return out_class[:b.n], (out_scores[:b.n] if want_scores else None)
+
+    # ------------------------------------------------------------------ trainer (replaces the vw learner process)
+    def train_begin(self, K: int, bits: int, resume=False):
+        check(lib().opal_train_begin(self._h, K, bits, int(resume)), self._h)
+        self.K, self.bits = K, bits
+
+    def train_batch(self, b: DeviceBatch, labels, reverse: bool, eta=0.5, l1=0.0, l2=0.0, sequential=False, want_pred=False):
+        """One pass over the batch in the order given. labels: VW class ids 1..K (numpy int32 or cuda tensor).
+        Returns the progressive predictions (class predicted before each example's update) or None."""
+        t = self.torch
+        if isinstance(labels, np.ndarray):
+            labels = t.from_numpy(np.ascontiguousarray(labels, dtype=np.int32)).to(self.device)
+        assert labels.dtype == t.int32 and labels.numel() >= b.n
+        pred = t.empty(max(b.n, 1), dtype=t.int32, device=self.device) if want_pred else None
+        check(lib().opal_train_batch(self._h, b.data.data_ptr(), b.nbytes, b.off.data_ptr(), b.len.data_ptr(),
+                                     labels.data_ptr(), b.n, int(reverse), eta, l1, l2, int(sequential),
+                                     pred.data_ptr() if want_pred else None), self._h)
+        return pred[:b.n] if want_pred else None
+
+    def get_weights(self, to_host=False):
+        """The 2^bits compact weight table (torch cuda tensor, or numpy when to_host)."""
+        t = self.torch
+        n = 1 << self.bits
+        if to_host:
+            out = np.empty(n, dtype=np.float32)
+            check(lib().opal_get_weights(self._h, out.ctypes.data, 0), self._h)
+            return out
+        out = t.empty(n, dtype=t.float32, device=self.device)
+        check(lib().opal_get_weights(self._h, out.data_ptr(), 1), self._h)
+        return out
+
+    def load_weights_sparse(self, idx: np.ndarray, val: np.ndarray, K: int, bits: int):
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        val = np.ascontiguousarray(val, dtype=np.float32)
+        assert idx.size == val.size
+        check(lib().opal_load_weights_sparse(self._h, idx.ctypes.data, val.ctypes.data, idx.size, K, bits), self._h)
+        self.K, self.bits = K, bits

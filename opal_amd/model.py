@@ -1,0 +1,90 @@
+"""On-disk model container for `vw-model_final.model` (the name opal.py:298,305 gives the regressor and
+opal.py:102-109 looks up by the `*_final.model` glob).
+
+The reference's file is whatever `vw -f` writes; VW is absent here (parity unpinned), so the primary format is a
+native container that holds exactly what the scoring kernel needs: bits, K (--oaa), the VW switches, and the
+compact weight table either dense (2^bits float32) or as (slot, weight) pairs when that is smaller.
+
+layout (little endian):  magic "OPALHIP1" | u32 version=1 | u32 bits | u32 K | u32 flags | f32 min_label | f32 max_label
+                         | u64 nnz | u32 dense(0/1) | u32 reserved | payload
+                         payload dense : float32[2^bits]          payload sparse: uint32 slot[nnz], float32 weight[nnz]
+flags: bit0 hash_all, bit1 add_constant, bit2 clip
+"""
+import struct
+
+import numpy as np
+
+MAGIC = b"OPALHIP1"
+_HDR = struct.Struct("<8sIIIIffQII")
+
+__all__ = ["save_model", "load_model", "read_header"]
+
+
+def _nonzero_chunks(w, chunk=1 << 27):
+    """(slot uint32, weight float32) of the non-zero entries of a 1-D tensor/array, scanning in chunks (torch.nonzero
+    refuses tensors with more than INT_MAX elements)."""
+    idx_parts, val_parts = [], []
+    n = w.shape[0]
+    is_np = isinstance(w, np.ndarray)
+    for s in range(0, n, chunk):
+        part = w[s:s + chunk]
+        if is_np:
+            nz = np.flatnonzero(part)
+            idx_parts.append((nz + s).astype(np.uint32))
+            val_parts.append(part[nz].astype(np.float32))
+        else:
+            nz = part.nonzero().squeeze(1)
+            idx_parts.append((nz + s).cpu().numpy().astype(np.uint32))
+            val_parts.append(part[nz].cpu().numpy().astype(np.float32))
+    return (np.concatenate(idx_parts) if idx_parts else np.zeros(0, np.uint32),
+            np.concatenate(val_parts) if val_parts else np.zeros(0, np.float32))
+
+
+def save_model(path, w, K, bits, hash_all=False, add_constant=True, clip=True, min_label=-1.0, max_label=1.0):
+    """w: the 2^bits table (numpy float32 or torch tensor, any device)."""
+    assert w.shape[0] == (1 << bits)
+    idx, val = _nonzero_chunks(w)
+    nnz = int(idx.size)
+    dense = nnz * 8 >= (1 << bits) * 4
+    flags = int(bool(hash_all)) | (int(bool(add_constant)) << 1) | (int(bool(clip)) << 2)
+    with open(path, "wb") as f:
+        f.write(_HDR.pack(MAGIC, 1, bits, K, flags, min_label, max_label, nnz, int(dense), 0))
+        if dense:
+            arr = w if isinstance(w, np.ndarray) else w.cpu().numpy()
+            np.ascontiguousarray(arr, dtype=np.float32).tofile(f)
+        else:
+            idx.tofile(f)
+            val.tofile(f)
+    return nnz
+
+
+def read_header(path):
+    with open(path, "rb") as f:
+        raw = f.read(_HDR.size)
+    if len(raw) < _HDR.size or raw[:8] != MAGIC:
+        raise RuntimeError("%s is not an opal_amd model (a VW binary regressor cannot be read: no vw to pin its layout)" % path)
+    magic, version, bits, K, flags, minl, maxl, nnz, dense, _ = _HDR.unpack(raw)
+    if version != 1:
+        raise RuntimeError("unsupported opal_amd model version %d" % version)
+    return dict(bits=bits, K=K, hash_all=bool(flags & 1), add_constant=bool(flags & 2), clip=bool(flags & 4),
+                min_label=minl, max_label=maxl, nnz=nnz, dense=bool(dense))
+
+
+def load_model(path, engine):
+    """Loads the model into the engine's GPU context (weights + VW switches). Returns the header dict."""
+    h = read_header(path)
+    with open(path, "rb") as f:
+        f.seek(_HDR.size)
+        if h["dense"]:
+            w = np.fromfile(f, dtype=np.float32, count=1 << h["bits"])
+            if w.size != (1 << h["bits"]):
+                raise RuntimeError("truncated model file " + path)
+            engine.load_weights(w, h["K"], h["bits"])
+        else:
+            idx = np.fromfile(f, dtype=np.uint32, count=h["nnz"])
+            val = np.fromfile(f, dtype=np.float32, count=h["nnz"])
+            if idx.size != h["nnz"] or val.size != h["nnz"]:
+                raise RuntimeError("truncated model file " + path)
+            engine.load_weights_sparse(idx, val, h["K"], h["bits"])
+    engine.set_vw_options(h["hash_all"], h["add_constant"], h["clip"], h["min_label"], h["max_label"])
+    return h

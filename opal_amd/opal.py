@@ -1,0 +1,371 @@
+#!/usr/bin/env python3
+"""Opal LDPC k-mer hash metagenomic classifier, MI355X-native: same CLI, flags, defaults and files as the
+reference's opal.py (frag / train / predict / eval / simulate, reference opal.py:511-645), with the feature
+extraction, hashing, scoring and learning done by hand-written HIP kernels in libopal_hip.so instead of Python string
+code piped into a `vw` process.
+
+Differences a user can see:
+  * no `vw` binary is needed or spawned; `<prefix>_vwps.log` holds this program's own progress lines;
+  * `vw-model_final.model` is an opal_amd container (opal_amd/model.py), not a VW regressor;
+  * run under `python -m torch.distributed.run --nproc-per-node N` to shard `predict` over N GPUs (no collectives).
+"""
+import argparse
+import glob
+import os
+import sys
+from datetime import datetime
+
+import numpy as np
+
+from . import drawfrag, fasta2skm, ldpc
+from . import model as model_io
+from .engine import Engine, PackedReads, Rng, parse_patterns
+from .fasta_functions import fasta_reader
+from .shard import gather_in_rank_order, shard_range
+
+__version__ = "1.0.0"
+
+
+# ------------------------------------------------------------------ small file helpers (reference opal.py:52-109)
+def unique_lines(file):
+    '''number of distinct raw lines (reference opal.py:52-58: compares lines including their newline)'''
+    seen = set()
+    with open(file) as f:
+        for line in f:
+            seen.add(line)
+    return len(seen)
+
+
+def safe_makedirs(directory):
+    if not os.path.exists(directory):
+        os.makedirs(directory)
+    return 0
+
+
+def extract_column_two(infile, outfile):
+    """cut -f2 infile > outfile (reference opal.py:65-74)"""
+    with open(infile, 'r') as inf, open(outfile, 'w') as outf:
+        for line in inf:
+            parts = line.split()
+            print(parts[1] if len(parts) > 1 else '', file=outf)
+
+
+def vw_class_to_taxid(inputfile, dicofile, outputfile):
+    '''class ids (one per line) -> taxids via the dico (reference opal.py:76-88); KeyError on an unknown class'''
+    dico = {}
+    with open(dicofile, "r") as fin:
+        for line in fin:
+            txid, vwid = line.strip().split()[:2]
+            dico[vwid] = txid
+    with open(inputfile, "r") as fin, open(outputfile, "w") as predout:
+        for line in fin:
+            predout.write("%s\n" % (dico[str(int(float(line.strip())))]))
+
+
+def get_fasta_and_taxid(directory):
+    try:
+        fasta = glob.glob(directory + "/*.fasta")[0]
+    except IndexError:
+        raise RuntimeError("Could not find fasta file in:" + directory)
+    taxids = os.path.splitext(fasta)[0] + ".taxid"
+    if not os.path.isfile(taxids):
+        raise RuntimeError("Could not find matching taxid: " + taxids)
+    return [fasta, taxids]
+
+
+def get_final_model(directory):
+    try:
+        return glob.glob(directory + "/*_final.model")[0]
+    except IndexError:
+        raise RuntimeError("Could not find final model file in: " + directory)
+
+
+def evaluate_predictions(reffile, predfile):
+    '''micro / macro / median per-class accuracy (reference opal.py:111-138)'''
+    with open(predfile, "r") as fin:
+        pred = fin.read().splitlines()
+    with open(reffile, "r") as fin:
+        ref = fin.read().splitlines()
+    correct = np.array([x == y for x, y in zip(pred, ref)], dtype=bool)
+    refs = np.array(ref[:len(correct)])
+    classes, inv = np.unique(refs, return_inverse=True)
+    species = np.bincount(inv, weights=correct, minlength=len(classes)) / np.maximum(np.bincount(inv, minlength=len(classes)), 1)
+    micro, macro, median = float(np.mean(correct)), float(np.mean(species)), float(np.median(species))
+    print("micro = {:.4f}".format(micro))
+    print("macro = {:.4f}".format(macro))
+    print("median = {:.4f}".format(median))
+    sys.stdout.flush()
+    return micro, macro, median
+
+
+def _dist():
+    """torch.distributed when launched with WORLD_SIZE>1 (one rank per GPU), else None."""
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return None, 0, 1, 0
+    import torch
+    import torch.distributed as dist
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not dist.is_initialized():
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return dist, dist.get_rank(), dist.get_world_size(), local
+
+
+# ------------------------------------------------------------------ frag (reference opal.py:141-206)
+def frag(test_dir, frag_dir, args):
+    fasta, taxids = get_fasta_and_taxid(test_dir)
+    safe_makedirs(frag_dir)
+    fasta_out = os.path.join(frag_dir, "test.fragments.fasta")
+    gi2taxid_out = os.path.join(frag_dir, "test.fragments.gi2taxid")
+    taxid_out = os.path.join(frag_dir, "test.fragments.taxid")
+    starttime = datetime.now()
+    print("================================================\nDrawing fragments\n{:%Y-%m-%d %H:%M:%S}\n".format(starttime))
+    print("frag_length = {}\ncoverage = {}".format(args.frag_length, args.coverage))
+    print("------------------------------------------------")
+    print("Fasta input:    {}\ntaxids input:   {}\n\nFasta output:   {}\ngi2taxid output:{}\ntaxids output:  {}".format(
+        fasta, taxids, fasta_out, gi2taxid_out, taxid_out))
+    sys.stdout.flush()
+    drawfrag.main(["-i", fasta, "-t", taxids, "-l", str(args.frag_length), "-c", str(args.coverage), "-o", fasta_out,
+                   "-g", gi2taxid_out, "-s", str(42)])        # seed 42: reference opal.py:187
+    extract_column_two(gi2taxid_out, taxid_out)
+    print("------------------------------------------------\nTotal wall clock runtime (sec): {}\n"
+          "================================================".format((datetime.now() - starttime).total_seconds()))
+    sys.stdout.flush()
+    return 0
+
+
+# ------------------------------------------------------------------ train (reference opal.py:208-389)
+def train(ref_dir, model_dir, args, engine=None):
+    frag_length, coverage, kmer = args.frag_length, args.coverage, args.kmer
+    row_weight, hierarchical, num_hash = args.row_weight, args.hierarchical_weight, args.num_hash
+    num_batches, num_passes, bits = args.num_batches, args.num_passes, args.bits
+    lambda1, lambda2, reverse = args.lambda1, args.lambda2, args.reverse_complement
+
+    fasta, taxids = get_fasta_and_taxid(ref_dir)
+    starttime = datetime.now()
+    if kmer % row_weight != 0:
+        raise ValueError("Row weight [{}] must divide into k-mer length [{}].".format(row_weight, kmer))
+    if hierarchical > 0:
+        if kmer % hierarchical != 0:
+            raise ValueError("Hierarchy middle level [{}] must divide into k-mer length [{}].".format(hierarchical, kmer))
+        if hierarchical % row_weight != 0:
+            raise ValueError("Row weight[{}] must divide into middle hierarchical structure weight [{}].".format(row_weight, hierarchical))
+    print("================================================\nTraining using Opal (MI355X-native learner)\n{:%Y-%m-%d %H:%M:%S}\n".format(starttime))
+    print("frag_length = {}\ncoverage:       {}\nreverse-complements: {}\nk-mer length:   {}".format(frag_length, coverage, reverse, kmer))
+    if hierarchical > 0:
+        print("hierarchical:   {}".format(hierarchical))
+    print("row weight:     {}\nnum hashes:     {}\nnum batches:    {}\nnum passes:     {}".format(row_weight, num_hash, num_batches, num_passes))
+    print("------------------------------------------------\nFasta input:    {}\ntaxids input:   {}\n"
+          "------------------------------------------------".format(fasta, taxids))
+    num_labels = unique_lines(taxids)                       # --oaa K (reference opal.py:288,311)
+    print("Number labels:  {}".format(num_labels))
+    sys.stdout.flush()
+
+    safe_makedirs(model_dir)
+    dico = os.path.join(model_dir, "vw-dico.txt")
+    model_prefix = os.path.join(model_dir, "vw-model")
+    pattern_file = os.path.join(model_dir, "patterns.txt")
+    ldpc.ldpc_write(k=kmer, t=row_weight, _m=num_hash, d=pattern_file)     # reference opal.py:301-302
+    with open(pattern_file) as f:
+        pos = parse_patterns(f.readlines(), kmer)
+
+    eng = engine or Engine(int(os.environ.get("LOCAL_RANK", "0")))
+    eng.set_patterns(pos, kmer)
+    eng.set_vw_options()
+    eng.train_begin(num_labels, bits)
+    final_model_file = model_prefix + "_final.model"
+    log = open(model_prefix + "_vwps.log", "w")
+    log.write("opal_amd learner: oaa=%d bits=%d l1=%g l2=%g passes=%d\n" % (num_labels, bits, lambda1, lambda2, num_passes))
+
+    with open(fasta, "r", encoding="latin-1") as f:
+        records = list(fasta_reader(f))
+    with open(taxids, "r") as f:
+        taxid_lines = [l.rstrip("\n") for l in f]
+
+    seed = 420
+    rng = Rng()
+    for i in range(num_batches):
+        seed = seed + 1                                      # 421, 422, ... (reference opal.py:329)
+        print("Drawing fragments for batch {}".format(i))
+        frags, labels = drawfrag.sample_fragments(records, taxid_lines, frag_length, coverage, seed, rng=rng)
+        batch_prefix = os.path.join(model_dir, "train.batch-{}".format(i))
+        taxid_batch = batch_prefix + ".taxid"
+        with open(taxid_batch, "w") as f:                     # same transient file the reference writes and deletes
+            f.write("".join("%s\n" % t for _, t in labels))
+        with open(taxid_batch, "r") as f:
+            label2vwid = fasta2skm.update_dictionary(f, dico)
+        vwid = np.array([label2vwid[t] for _, t in labels], dtype=np.int32)
+        if vwid.size and vwid.max() > num_labels:
+            raise ValueError("class id %d exceeds --oaa %d" % (vwid.max(), num_labels))
+        print("Getting training set ...")
+        pr = PackedReads.from_sequences([s.encode("latin-1") for s in frags])
+        print("Shuffling training set ...")
+        perm = rng.shuffle_perm(len(frags)).astype(np.int64)   # random.shuffle on the same stream (reference opal.py:363)
+        pr = PackedReads(pr.data, np.ascontiguousarray(pr.off[perm]), np.ascontiguousarray(pr.len[perm]))
+        vwid = np.ascontiguousarray(vwid[perm])
+        print("Training on the GPU ...")
+        sys.stdout.flush()
+        batch = eng.upload(pr)
+        for p in range(max(1, num_passes)):
+            pred = eng.train_batch(batch, vwid, reverse, eta=0.5, l1=lambda1, l2=lambda2, want_pred=True)
+            err = float((pred.cpu().numpy() != vwid).mean()) if len(frags) else 0.0
+            msg = "batch %d pass %d: %d examples, progressive error %.4f" % (i, p, len(frags), err)
+            print(msg)
+            log.write(msg + "\n")
+        os.remove(taxid_batch)
+    w = eng.get_weights()
+    nnz = model_io.save_model(final_model_file, w, num_labels, bits)
+    log.write("saved %s (%d non-zero weights)\n" % (final_model_file, nnz))
+    log.close()
+    print("------------------------------------------------\nTotal wall clock runtime (sec): {}\n"
+          "================================================".format((datetime.now() - starttime).total_seconds()))
+    sys.stdout.flush()
+    return 0
+
+
+# ------------------------------------------------------------------ predict (reference opal.py:392-493)
+def predict(model_dir, test_dir, predict_dir, args, engine=None, chunk=2_000_000):
+    kmer, reverse = args.kmer, args.reverse_complement
+    try:
+        fasta = glob.glob(test_dir + "/*.fasta")[0]
+    except IndexError:
+        raise RuntimeError("No fasta file found in: " + test_dir)
+    model = get_final_model(model_dir)
+    dico = os.path.join(model_dir, "vw-dico.txt")
+    pattern_file = os.path.join(model_dir, "patterns.txt")
+    starttime = datetime.now()
+    dist, rank, world, local = _dist()
+    if rank == 0:
+        print("================================================\nPredicting using Opal (MI355X-native scorer)\n{:%Y-%m-%d %H:%M:%S}\n".format(starttime))
+        print("k-mer length:   {}\n------------------------------------------------".format(kmer))
+        print("Fasta input:    {}\nModel used:     {}\nDict used:      {}\nLDPC patterns:  {}\nreverse-complements: {}".format(
+            fasta, model, dico, pattern_file, reverse))
+        print("------------------------------------------------")
+        sys.stdout.flush()
+    safe_makedirs(predict_dir)
+    prefix = os.path.join(predict_dir, "test.fragments-db")
+    prediction_file = prefix + ".preds.vw"
+
+    with open(pattern_file, "r") as f:
+        pos = parse_patterns(f.readlines(), kmer)
+    eng = engine or Engine(local)
+    eng.set_patterns(pos, kmer)
+    hdr = model_io.load_model(model, eng)
+    with open(fasta, "r", encoding="latin-1") as f:
+        seqs = [s.encode("latin-1") for _, s in fasta_reader(f)]
+    lo, hi = shard_range(len(seqs), rank, world)            # contiguous fragment range per rank
+    out = []
+    for c0 in range(lo, hi, chunk):
+        part = seqs[c0:min(hi, c0 + chunk)]
+        cls, _ = eng.predict(eng.upload(PackedReads.from_sequences(part)), reverse)
+        out.append(cls.cpu().numpy())
+    local_cls = np.concatenate(out) if out else np.zeros(0, dtype=np.int32)
+    full = gather_in_rank_order(local_cls, dist)
+    if rank == 0:
+        with open(prefix + "_vwps.log", "w") as log:
+            log.write("opal_amd scorer: %d fragments, oaa=%d bits=%d, kernel %s, %d rank(s)\n" % (
+                len(seqs), hdr["K"], hdr["bits"], eng.predict_kernel_name(), world))
+        with open(prediction_file, "w") as f:                # what `vw -p` writes: one class id per line
+            f.write("".join("%d\n" % c for c in full.tolist()))
+        vw_class_to_taxid(prediction_file, dico, prefix + '.preds.taxid')
+        print("------------------------------------------------\nPredicted labels:   {}\nTotal wall clock runtime (sec): {}\n"
+              "================================================".format(prefix + '.preds.taxid', (datetime.now() - starttime).total_seconds()))
+        sys.stdout.flush()
+    if dist:
+        dist.barrier()
+    return prefix + '.preds.taxid'
+
+
+class ArgClass:
+    '''holder so that flag definitions are shared between sub-parsers'''
+    def __init__(self, *args, **kwargs):
+        self.args = args
+        self.kwargs = kwargs
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(formatter_class=argparse.RawTextHelpFormatter, description=__doc__)
+    parser.add_argument('--version', action='version', version='%(prog)s {version}'.format(version=__version__))
+    # same flags and defaults as reference opal.py:519-545
+    frag_length_arg = ArgClass("-l", "--frag-length", help="length of fragments to be drawn from fasta", type=int, default=64)
+    kmer_arg = ArgClass("-k", "--kmer", help="length of k-mers used", type=int, default=64)
+    coverage_arg = ArgClass("-c", "--coverage", help="number/fraction of times each location in a fragment should be covered by a k-mer", type=float, default=15.0)
+    reverse_complement_arg = ArgClass("-r", "--reverse-complement", help="Also trains and evaluates on reverse complements of ACGT DNA strings", action="store_true")
+    hierarchical_arg = ArgClass("--hierarchical-weight", help="intermediate organization of positions chosen in the k-mer in row_weight; should be a multiple of row_weight and a divisor of k-mer length if set", type=int, default=-1)
+    row_weight_arg = ArgClass("--row-weight", help="the number of positions that will be randomly chosen in the contiguous k-mer; k-mer length should be a multiple of row_weight", type=int, default=16)
+    num_hash_arg = ArgClass("--num-hash", help="number of k-mer hashing functions to get features", type=int, default=8)
+    num_batches_arg = ArgClass("--num-batches", help="Number of times to generate a random batch of training data", type=int, default=1)
+    num_passes_arg = ArgClass("--num-passes", help="Number of passes in each training batch", type=int, default=1)
+    bits_arg = ArgClass("--bits", help="Number of bits used in the model's hash table", type=int, default=31)
+    lambda1_arg = ArgClass("--lambda1", help="l1 training parameter", type=float, default=0.)
+    lambda2_arg = ArgClass("--lambda2", help="l2 training parameter", type=float, default=0.)
+    train_args = [frag_length_arg, coverage_arg, kmer_arg, reverse_complement_arg, num_batches_arg, num_passes_arg,
+                  num_hash_arg, row_weight_arg, hierarchical_arg, bits_arg, lambda1_arg, lambda2_arg]
+
+    sub = parser.add_subparsers(help="sub-commands", dest="mode")
+    fmt = argparse.ArgumentDefaultsHelpFormatter
+    p = sub.add_parser("frag", help="Fragment a fasta file into substrings for training/testing", formatter_class=fmt)
+    p.add_argument("test_dir", help="Input directory for test data")
+    p.add_argument("frag_dir", help="Output directory for fasta fragments")
+    for a in (frag_length_arg, coverage_arg):
+        p.add_argument(*a.args, **a.kwargs)
+    p = sub.add_parser("train", help="Train a model using Opal hashes", formatter_class=fmt)
+    p.add_argument("train_dir", help="Input directory for train data")
+    p.add_argument("model_dir", help="Output directory for the model")
+    for a in train_args:
+        p.add_argument(*a.args, **a.kwargs)
+    p = sub.add_parser("predict", help="Predict metagenomic classifications given a Opal model", formatter_class=fmt)
+    p.add_argument("model_dir", help="Input directory for the model")
+    p.add_argument("test_dir", help="Input directory for already fragmented test data")
+    p.add_argument("predict_dir", help="Output directory for predictions")
+    for a in (reverse_complement_arg, kmer_arg):
+        p.add_argument(*a.args, **a.kwargs)
+    p = sub.add_parser('eval', help="Evaluate quality of predictions given a reference", formatter_class=fmt)
+    p.add_argument("reference_file", help="Gold standard labels")
+    p.add_argument("predicted_labels", help="Predicted labels")
+    p = sub.add_parser('simulate', help="Run a full pipeline of frag, train, predict, and eval", formatter_class=fmt)
+    p.add_argument("test_dir", help="Input directory for test data")
+    p.add_argument("train_dir", help="Input directory for train data")
+    p.add_argument("out_dir", help="Output directory for all steps")
+    p.add_argument("--do-not-fragment", help="If set, will use test_dir fasta files as is without fragmenting", action="store_true")
+    for a in train_args:
+        p.add_argument(*a.args, **a.kwargs)
+    return parser
+
+
+def main(argv):
+    args = build_parser().parse_args(argv)
+    print(args)
+    sys.stdout.flush()
+    mode = args.mode
+    if mode == "simulate":
+        fullstarttime = datetime.now()
+        print("Full simulation\n{:%Y-%m-%d %H:%M:%S}\nFragment mode: {}".format(fullstarttime, not args.do_not_fragment))
+        frag_dir = os.path.join(args.out_dir, '1frag')
+        model_dir = os.path.join(args.out_dir, '2model')
+        predict_dir = os.path.join(args.out_dir, '3predict')
+        if args.do_not_fragment:
+            train(args.train_dir, model_dir, args)
+            pf = predict(model_dir, args.test_dir, predict_dir, args)
+            _, rf = get_fasta_and_taxid(args.test_dir)
+        else:
+            frag(args.test_dir, frag_dir, args)
+            train(args.train_dir, model_dir, args)
+            pf = predict(model_dir, frag_dir, predict_dir, args)
+            _, rf = get_fasta_and_taxid(frag_dir)
+        print("Evaluation reference file: " + rf)
+        sys.stdout.flush()
+        evaluate_predictions(rf, pf)
+        print("Total full sim wall clock runtime (sec): {}".format((datetime.now() - fullstarttime).total_seconds()))
+    elif mode == "frag":
+        frag(args.test_dir, args.frag_dir, args)
+    elif mode == "train":
+        train(args.train_dir, args.model_dir, args)
+    elif mode == "predict":
+        predict(args.model_dir, args.test_dir, args.predict_dir, args)
+    elif mode == "eval":
+        evaluate_predictions(args.reference_file, args.predicted_labels)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

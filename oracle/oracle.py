@@ -65,6 +65,10 @@ def lib():
         L.orc_features_batch.restype = C.c_uint64
         L.orc_features_batch.argtypes = [C.c_void_p, u64p, C.c_uint64, C.c_int, i32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, u64p, C.c_void_p, C.c_int]
+        L.orc_train.restype = None
+        L.orc_train.argtypes = [C.c_void_p, u64p, C.c_uint64, C.c_int, i32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_void_p, C.c_void_p, C.c_int, C.c_int, i32p, C.c_float, C.c_float, C.c_float,
+                                C.c_float, C.c_float, i32p]
         L.orc_rng_new.restype = C.c_void_p
         L.orc_rng_free.argtypes = [C.c_void_p]
         L.orc_rng_seed_limbs.argtypes = [C.c_void_p, u32p, C.c_int]
@@ -188,6 +192,22 @@ def predict(seqs, k, pos, reverse, w, K, bits, add_constant=True, clip=True, min
                         w.ctypes.data, K, bits, int(add_constant), int(clip), min_label, max_label,
                         _p(cls, C.c_int32), sc.ctypes.data if want_scores else None, nthreads)
     return cls[:n], (sc[:n] if want_scores else None), int(tot)
+
+
+def train(seqs, labels, k, pos, reverse, w, g2, K, bits, eta=0.5, l1=0.0, l2=0.0, min_label=-1.0, max_label=1.0,
+          hash_all=False):
+    """Sequential restatement of the trainer (updates w and g2 in place). Returns progressive predictions."""
+    L = lib()
+    blob, off = seqs if isinstance(seqs, tuple) else _concat(seqs)
+    n = len(off) - 1
+    P, t = pos.shape
+    assert w.dtype == np.float32 and g2.dtype == np.float32 and w.size == g2.size == (1 << bits)
+    lab = np.ascontiguousarray(labels, dtype=np.int32)
+    pred = np.zeros(max(n, 1), dtype=np.int32)
+    L.orc_train(blob.ctypes.data, _p(off, C.c_uint64), n, k, _p(pos, C.c_int32), P, t, int(reverse), int(hash_all),
+                w.ctypes.data, g2.ctypes.data, K, bits, _p(lab, C.c_int32), eta, l1, l2, min_label, max_label,
+                _p(pred, C.c_int32))
+    return pred[:n]
 
 
 def max_threads():

@@ -1,0 +1,154 @@
+"""GPU tests of the native OAA learner, the model container and the CLI pipeline.
+
+The learner is this project's own VW-like rule (VW is absent: parity unpinned), so the checks are: (1) the HIP kernel
+in `sequential` mode against the oracle's sequential restatement of the same rule (tolerance 2e-4 relative: GPU expf
+differs from libm's in the last bits), (2) the concurrent mode learns (held-out accuracy), (3) files and round trips.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import opal_amd
+    opal_amd.lib()
+    return opal_amd
+
+
+def _patterns(amd, golden_dir, fname, k):
+    with open(os.path.join(golden_dir, fname)) as f:
+        return amd.parse_patterns(f.readlines(), k)
+
+
+@pytest.mark.parametrize("K,bits,l1,l2", [(10, 12, 0.0, 0.0), (356, 16, 0.0, 0.0), (7, 14, 1e-4, 1e-3), (1564, 18, 0.0, 0.0)])
+def test_sequential_training_matches_oracle(amd, oracle, golden_dir, K, bits, l1, l2):
+    rng = np.random.default_rng(K + bits)
+    pos = _patterns(amd, golden_dir, "patterns_k64_t16_m1_s7.txt", 64)
+    seqs = [bytes(rng.choice(ACGT, size=200)) for _ in range(24)]
+    seqs[2] = b"A" * 200                       # every window identical: the same row 137 times in a row
+    seqs[3] = b"ACAC" * 50                     # two alternating rows
+    seqs[4] = seqs[4].lower()                  # raw path
+    seqs[5] = seqs[5][:30]                     # no k-mer: only the constant feature
+    seqs += seqs[:6]                           # repeats: weights already touched
+    labels = rng.integers(1, K + 1, size=len(seqs)).astype(np.int32)
+    eng = amd.Engine(0)
+    eng.set_patterns(pos, 64)
+    eng.train_begin(K, bits)
+    batch = eng.upload(amd.PackedReads.from_sequences(seqs))
+    w = np.zeros(1 << bits, dtype=np.float32)
+    g2 = np.zeros(1 << bits, dtype=np.float32)
+    for p in range(2):                         # two passes, like --num-passes 2
+        pred = eng.train_batch(batch, labels, True, eta=0.5, l1=l1, l2=l2, sequential=True, want_pred=True)
+        opred = oracle.train(seqs, labels, 64, pos, True, w, g2, K, bits, eta=0.5, l1=l1, l2=l2)
+        gw = eng.get_weights(to_host=True)
+        assert np.allclose(gw, w, rtol=2e-4, atol=1e-6), (p, np.abs(gw - w).max())
+        assert (pred.cpu().numpy() == opred).mean() > 0.9      # ties between near-equal scores may flip
+    assert np.count_nonzero(w) > 0
+    # the trained table is immediately usable by predict (mirror padding refreshed)
+    cls, sc = eng.predict(batch, True, want_scores=True)
+    ocls, osc, _ = oracle.predict(seqs, 64, pos, True, gw, K, bits)
+    assert np.array_equal(sc.cpu().numpy(), osc) and np.array_equal(cls.cpu().numpy(), ocls)
+    eng.close()
+
+
+def _make_genomes(rng, n_genomes, glen, divergence):
+    """n_genomes related genomes: mutated copies of a common ancestor (shared k-mers make the task non-trivial)."""
+    anc = rng.integers(0, 4, size=glen, dtype=np.uint8)
+    out = []
+    for _ in range(n_genomes):
+        g = anc.copy()
+        m = rng.random(glen) < divergence
+        g[m] = (g[m] + rng.integers(1, 4, size=int(m.sum()))) % 4
+        out.append(bytes(ACGT[g]))
+    return out
+
+
+def test_concurrent_training_learns_and_model_roundtrip(amd, golden_dir, tmp_path):
+    from opal_amd import model as model_io
+    rng = np.random.default_rng(5)
+    K, bits, L = 12, 26, 200
+    genomes = _make_genomes(rng, K, 30_000, 0.08)
+    pos = _patterns(amd, golden_dir, "patterns_k64_t16_m1_s7.txt", 64)
+
+    def draw(n):
+        g = rng.integers(0, K, size=n)
+        p = rng.integers(0, 30_000 - L, size=n)
+        return [genomes[a][b:b + L] for a, b in zip(g, p)], (g + 1).astype(np.int32)
+
+    eng = amd.Engine(0)
+    eng.set_patterns(pos, 64)
+    eng.train_begin(K, bits)
+    tr_seqs, tr_lab = draw(20_000)
+    batch = eng.upload(amd.PackedReads.from_sequences(tr_seqs))
+    errs = []
+    for _ in range(2):
+        pred = eng.train_batch(batch, tr_lab, True, want_pred=True)
+        errs.append(float((pred.cpu().numpy() != tr_lab).mean()))
+    assert errs[1] < errs[0]
+    te_seqs, te_lab = draw(4_000)
+    tb = eng.upload(amd.PackedReads.from_sequences(te_seqs))
+    cls, _ = eng.predict(tb, True)
+    acc = float((cls.cpu().numpy() == te_lab).mean())
+    assert acc > 0.9, acc
+    # container round trip (sparse payload) gives identical predictions
+    path = str(tmp_path / "vw-model_final.model")
+    nnz = model_io.save_model(path, eng.get_weights(), K, bits)
+    assert 0 < nnz < (1 << bits) // 2 and not model_io.read_header(path)["dense"]
+    e2 = amd.Engine(0)
+    e2.set_patterns(pos, 64)
+    hdr = model_io.load_model(path, e2)
+    assert (hdr["K"], hdr["bits"]) == (K, bits)
+    cls2, _ = e2.predict(tb, True)
+    assert np.array_equal(cls2.cpu().numpy(), cls.cpu().numpy())
+    # dense payload
+    w = (rng.standard_normal(1 << 12) * 0.1).astype(np.float32)
+    p2 = str(tmp_path / "dense_final.model")
+    model_io.save_model(p2, w, 5, 12, clip=False)
+    h2 = model_io.load_model(p2, e2)
+    assert h2["dense"] and not h2["clip"]
+    assert np.array_equal(e2.get_weights(to_host=True), w)
+    eng.close()
+    e2.close()
+
+
+def test_cli_simulate_pipeline(amd, tmp_path, capsys):
+    """opal.py simulate: frag -> train -> predict -> eval with the reference's directory/file contract."""
+    from opal_amd import opal
+    rng = np.random.default_rng(9)
+    K = 6
+    genomes = _make_genomes(rng, K, 20_000, 0.10)
+    taxids = ["562", "1280", "1313", "4932", "9606", "562x"]
+    for d in ("train", "test"):
+        os.makedirs(tmp_path / d)
+        with open(tmp_path / d / "A1.fasta", "w") as f:
+            for i, g in enumerate(genomes):
+                f.write(">gi|%d| genome %d\n" % (i, i))
+                f.write("\n".join(g[j:j + 70].decode() for j in range(0, len(g), 70)) + "\n")
+        with open(tmp_path / d / "A1.taxid", "w") as f:
+            f.write("".join(t + "\n" for t in taxids))
+    out = tmp_path / "out"
+    np.random.seed(1)
+    opal.main(["simulate", str(tmp_path / "test"), str(tmp_path / "train"), str(out), "-r", "-l", "200", "-c", "2",
+               "--num-hash", "2", "--num-batches", "2", "--bits", "22"])
+    for rel in ("1frag/test.fragments.fasta", "1frag/test.fragments.gi2taxid", "1frag/test.fragments.taxid",
+                "2model/patterns.txt", "2model/vw-dico.txt", "2model/vw-model_final.model", "2model/vw-model_vwps.log",
+                "3predict/test.fragments-db.preds.vw", "3predict/test.fragments-db.preds.taxid",
+                "3predict/test.fragments-db_vwps.log"):
+        assert os.path.isfile(out / rel), rel
+    assert not list((out / "2model").glob("train.batch-*"))         # transient batch files removed
+    assert open(out / "2model" / "patterns.txt").readline() == "3 16\n"
+    assert open(out / "2model" / "vw-dico.txt").read().count("\n") == K
+    text = capsys.readouterr().out
+    micro = float([l for l in text.splitlines() if l.startswith("micro = ")][-1].split("=")[1])
+    assert micro > 0.9, text[-2000:]
+    ref = open(out / "1frag" / "test.fragments.taxid").read().splitlines()
+    pred = open(out / "3predict" / "test.fragments-db.preds.taxid").read().splitlines()
+    assert len(ref) == len(pred) == 6 * 200
+    # eval sub-command on the same files prints the same numbers
+    opal.main(["eval", str(out / "1frag" / "test.fragments.taxid"), str(out / "3predict" / "test.fragments-db.preds.taxid")])
+    assert "micro = %.4f" % micro in capsys.readouterr().out
