@@ -14,7 +14,9 @@
  *   - one ctx per GPU, not thread-safe; different ctxs may be driven concurrently.
  *
  * Fragment batch layout in HBM ("reads"):
- *   d_frag_off[i]  byte offset of fragment i inside d_reads
+ *   d_frag_off[i]  where fragment i starts inside d_reads: a BYTE offset for raw fragments, a BASE offset (4 per byte)
+ *                  for 2-bit packed ones, so that a packed fragment may alias any window of a packed genome that lives
+ *                  in the same buffer (zero-copy fragment sampling: offset = 4*genome_byte_offset + position)
  *   d_frag_len[i]  low 31 bits: length in bases; bit 31 (OPAL_RAW_FLAG) set -> the fragment is stored as raw
  *                  ASCII bytes (one per base: anything that is not upper-case A/C/G/T lives here), clear -> it is
  *                  2-bit packed, 4 bases per byte, base j of the fragment in bits 2*(j&3) of byte j>>2, A=0 C=1 G=2 T=3.

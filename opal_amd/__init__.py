@@ -6,6 +6,6 @@ Layout:
   engine.py        per-GPU driver (torch is used for device buffers and streams only)
 """
 from ._lib import OpalError, lib  # noqa: F401
-from .engine import Engine, PackedReads, Rng, parse_patterns  # noqa: F401
+from .engine import Engine, GenomeSet, PackedReads, Rng, parse_patterns  # noqa: F401
 
 __version__ = "0.1.0"

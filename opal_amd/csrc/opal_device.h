@@ -43,8 +43,10 @@ __device__ __forceinline__ uint32_t rc_byte(uint32_t c)
 }
 
 // Loads bytes [i0, i0+cnt) of strand `strand` of one fragment into LDS as the ASCII text the reference sees.
-__device__ __forceinline__ void load_tile(uint8_t *sq, const uint8_t *src, uint32_t len, bool raw, int strand,
-                                          uint32_t i0, uint32_t cnt, int lane)
+// `shift` (0..3) = position of the fragment's first base inside its first packed byte (packed fragments may start
+// at any base of a packed genome that lives in the same buffer).
+__device__ __forceinline__ void load_tile(uint8_t *sq, const uint8_t *src, uint32_t len, bool raw, uint32_t shift,
+                                          int strand, uint32_t i0, uint32_t cnt, int lane)
 {
     for (uint32_t i = lane; i < cnt; i += WAVE) {
         const uint32_t p = i0 + i;
@@ -53,12 +55,35 @@ __device__ __forceinline__ void load_tile(uint8_t *sq, const uint8_t *src, uint3
         if (raw) {
             c = src[sp];
         } else {
-            const uint32_t code = (src[sp >> 2] >> ((sp & 3u) * 2u)) & 3u;
+            const uint32_t q = sp + shift;
+            const uint32_t code = (src[q >> 2] >> ((q & 3u) * 2u)) & 3u;
             c = (0x54474341u >> (code * 8u)) & 0xffu;  // "ACGT"
         }
         if (strand) c = rc_byte(c);
         sq[i] = (uint8_t)c;
     }
+}
+
+// Resolves fragment `frag` of a batch: raw fragments are addressed in BYTES, packed ones in BASES (so that a packed
+// fragment can alias any window of a packed genome).  A fragment that would reach outside the buffer gets len 0.
+struct FragRef {
+    const uint8_t *src;
+    uint32_t len, shift;
+    bool raw;
+};
+__device__ __forceinline__ FragRef locate_fragment(const Batch &B, uint64_t frag)
+{
+    FragRef r;
+    const uint32_t lw = B.len[frag];
+    r.raw = (lw & OPAL_RAW_FLAG) != 0;
+    r.len = lw & ~OPAL_RAW_FLAG;
+    const uint64_t off = B.off[frag];
+    uint64_t first, last;  // byte range [first, last)
+    if (r.raw) { first = off; last = off + r.len; r.shift = 0; }
+    else { first = off >> 2; last = (off + r.len + 3) >> 2; r.shift = (uint32_t)(off & 3); }
+    if (last > B.reads_bytes || first > last) { r.len = 0; first = 0; }
+    r.src = B.reads + first;
+    return r;
 }
 
 // ------------------------------------------------------------------------------------------ MurmurHash3_x86_32
@@ -141,13 +166,10 @@ __device__ __forceinline__ void walk_fragment(const Batch &B, const Geom &G, uin
                                               bool add_const, uint32_t const_idx, uint8_t *sq, uint32_t *hb, int lane,
                                               Flush &&flush)
 {
-    const uint32_t lw = B.len[frag];
-    const bool raw = (lw & OPAL_RAW_FLAG) != 0;
-    uint32_t len = lw & ~OPAL_RAW_FLAG;
-    const uint64_t off = B.off[frag];
-    const uint64_t nbytes = raw ? (uint64_t)len : ((uint64_t)len + 3) / 4;
-    if (off > B.reads_bytes || nbytes > B.reads_bytes - off) len = 0;  // never read outside the batch buffer
-    const uint8_t *src = B.reads + off;
+    const FragRef fr = locate_fragment(B, frag);  // never reads outside the batch buffer
+    const bool raw = fr.raw;
+    const uint32_t len = fr.len;
+    const uint8_t *src = fr.src;
     const int k = G.k, P = G.P, t = G.t;
     const bool fast16 = (t == 16) && (P <= 10) && !raw;
     const bool digit_rule = raw && !G.hash_all;
@@ -161,7 +183,7 @@ __device__ __forceinline__ void walk_fragment(const Batch &B, const Geom &G, uin
                 uint32_t room = (HB - fill) / (uint32_t)P;
                 if (room < min(W - w0, (uint32_t)WAVE)) { flush(fill); fill = 0; room = HB / (uint32_t)P; }
                 const uint32_t tw = min(min(W - w0, tw_seq), room);
-                load_tile(sq, src, len, raw, s, w0, tw + (uint32_t)k - 1u, lane);
+                load_tile(sq, src, len, raw, fr.shift, s, w0, tw + (uint32_t)k - 1u, lane);
                 // wave-private LDS: every lane's ds_write retires before the next ds_read issues (same wave,
                 // in-order LDS queue); the fence only stops the compiler from reordering.
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

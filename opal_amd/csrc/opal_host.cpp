@@ -51,7 +51,7 @@ extern "C" int opal_pack_reads(const uint8_t *seqs, const uint64_t *seq_off, uin
         for (uint64_t j = 0; j < len; j++)
             if (base_code(s[j]) < 0) { acgt = false; break; }
         const uint64_t nbytes = acgt ? (len + 3) / 4 : len;
-        if (frag_off) frag_off[i] = o;
+        if (frag_off) frag_off[i] = acgt ? o * 4 : o;   // packed fragments are addressed in bases, raw ones in bytes
         if (frag_len) frag_len[i] = (uint32_t)len | (acgt ? 0u : OPAL_RAW_FLAG);
         if (out) {
             if (o + nbytes > out_cap) return opal::fail(nullptr, OPAL_ERANGE, "opal_pack_reads: output buffer too small");

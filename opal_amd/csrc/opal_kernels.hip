@@ -57,21 +57,18 @@ __global__ __launch_bounds__(BLOCK) void emit_names_kernel(Batch B, Geom G, cons
     const uint64_t nwaves = (uint64_t)gridDim.x * WPB;
     const int k = G.k, P = G.P, t = G.t;
     for (uint64_t frag = (uint64_t)blockIdx.x * WPB + wv; frag < B.n; frag += nwaves) {
-        const uint32_t lw = B.len[frag];
-        const bool raw = (lw & OPAL_RAW_FLAG) != 0;
-        uint32_t len = lw & ~OPAL_RAW_FLAG;
-        const uint64_t off = B.off[frag];
-        const uint64_t nbytes = raw ? (uint64_t)len : ((uint64_t)len + 3) / 4;
-        if (off > B.reads_bytes || nbytes > B.reads_bytes - off) len = 0;
+        const FragRef fr = locate_fragment(B, frag);
+        const bool raw = fr.raw;
+        const uint32_t len = fr.len;
         if (len < (uint32_t)k) continue;
-        const uint8_t *src = B.reads + off;
+        const uint8_t *src = fr.src;
         const uint32_t W = len - (uint32_t)k + 1u;
         const uint32_t tw_seq = (uint32_t)(SEQB - k + 1);
         uint64_t f0 = out_off[frag];
         for (int s = 0; s < (G.reverse ? 2 : 1); s++) {
             for (uint32_t w0 = 0; w0 < W; w0 += tw_seq) {
                 const uint32_t tw = min(W - w0, tw_seq);
-                load_tile(sq, src, len, raw, s, w0, tw + (uint32_t)k - 1u, lane);
+                load_tile(sq, src, len, raw, fr.shift, s, w0, tw + (uint32_t)k - 1u, lane);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 for (uint32_t i = lane; i < tw * (uint32_t)P; i += WAVE) {

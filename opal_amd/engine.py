@@ -10,7 +10,7 @@ import numpy as np
 from . import _lib
 from ._lib import check, lib
 
-__all__ = ["PackedReads", "Rng", "Engine", "parse_patterns"]
+__all__ = ["PackedReads", "Rng", "Engine", "GenomeSet", "parse_patterns"]
 
 
 def parse_patterns(lines, kmer):
@@ -72,7 +72,7 @@ class PackedReads:
         pad[:, :L] = codes
         q = pad.reshape(n, nb, 4)
         data = (q[:, :, 0] | (q[:, :, 1] << 2) | (q[:, :, 2] << 4) | (q[:, :, 3] << 6)).astype(np.uint8).reshape(-1)
-        off = (np.arange(n, dtype=np.uint64) * np.uint64(nb))
+        off = (np.arange(n, dtype=np.uint64) * np.uint64(nb * 4))   # packed fragments are addressed in bases
         return PackedReads(np.ascontiguousarray(data), off, np.full(n, L, dtype=np.uint32))
 
 
@@ -125,6 +125,27 @@ class Rng:
 class DeviceBatch:
     def __init__(self, data, off, length, n, nbytes):
         self.data, self.off, self.len, self.n, self.nbytes = data, off, length, n, nbytes
+
+
+class GenomeSet:
+    """Genomes resident in HBM (packed once); fragments are (offset, length) views into them: sampling a batch
+    uploads 12 bytes per fragment instead of its bases (zero-copy `drawfrag`, reference util/drawfrag.py:38-39)."""
+
+    def __init__(self, engine, pr: PackedReads):
+        self.engine = engine
+        self.host = pr
+        self.dev = engine.upload(pr)
+        self.lengths = (pr.len & np.uint32(0x7FFFFFFF)).astype(np.uint64)
+
+    def fragments(self, pos, gen, frag_len: int) -> "DeviceBatch":
+        """pos, gen: arrays from Rng.sample_positions (position inside the genome, genome index)."""
+        t = self.engine.torch
+        gen = np.asarray(gen, dtype=np.int64)
+        off = self.host.off[gen] + np.asarray(pos, dtype=np.uint64)      # bases for packed genomes, bytes for raw ones
+        ln = (self.host.len[gen] & np.uint32(_lib.RAW_FLAG)) | np.uint32(frag_len)
+        d_off = t.from_numpy(np.ascontiguousarray(off).view(np.int64)).to(self.engine.device)
+        d_len = t.from_numpy(np.ascontiguousarray(ln).view(np.int32)).to(self.engine.device)
+        return DeviceBatch(self.dev.data, d_off, d_len, int(len(off)), self.dev.nbytes)
 
 
 class Engine:

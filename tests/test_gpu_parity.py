@@ -229,3 +229,32 @@ def test_properties_at_scale(amd, eng, oracle, golden_dir):
     ocls, osc, _ = oracle.predict((blob[:m * L + 1], soff[:m + 1]), 64, pos, True, w, K, bits, clip=False, nthreads=0)
     assert np.array_equal(sc.cpu().numpy()[:m], osc) and np.array_equal(cls.cpu().numpy()[:m], ocls)
     eng.set_vw_options()
+
+
+def test_zero_copy_fragments_from_resident_genomes(amd, eng, oracle, golden_dir):
+    """drawfrag on the GPU side: fragments are views (genome offset + position) into genomes packed once in HBM;
+    features and predictions equal those of the explicitly cut fragments (reference util/drawfrag.py:38-39)."""
+    rng = np.random.default_rng(77)
+    pos = _patterns(amd, golden_dir, "patterns_k64_t16_m1_s7.txt", 64)
+    eng.set_patterns(pos, 64)
+    genomes = [bytes(rng.choice(ACGT, size=L)) for L in (5003, 777, 150, 4096)]
+    genomes[1] = genomes[1][:300] + b"NNNNnnacgt" + genomes[1][310:]      # a raw genome
+    gs = amd.GenomeSet(eng, amd.PackedReads.from_sequences(genomes))
+    r = amd.Rng(421)
+    p, g = r.sample_positions([len(x) for x in genomes], 200, 3.0)
+    frags = [genomes[gi][pi:pi + 200] for pi, gi in zip(p.tolist(), g.tolist())]
+    assert len(frags) > 100 and any(pi % 4 for pi in p.tolist())
+    view = gs.fragments(p, g, 200)
+    idx, off = eng.features(view, True, 31)
+    oidx, ooff = oracle.features_batch(frags, 64, pos, True, 31)
+    assert np.array_equal(off.cpu().numpy().view(np.uint64), ooff) and np.array_equal(_u32(idx), oidx)
+    K, bits = 20, 16
+    w = (rng.standard_normal(1 << bits) * 0.05).astype(np.float32)
+    eng.load_weights(w, K, bits)
+    cls, sc = eng.predict(view, True, want_scores=True)
+    ocls, osc, _ = oracle.predict(frags, 64, pos, True, w, K, bits)
+    assert np.array_equal(sc.cpu().numpy(), osc) and np.array_equal(cls.cpu().numpy(), ocls)
+    # a view that would run past the buffer is treated as empty, never read
+    bad = gs.fragments(np.array([4000]), np.array([3]), 2000)
+    idx2, off2 = eng.features(bad, True, 31)
+    assert off2.cpu().numpy().tolist()[0] == 0

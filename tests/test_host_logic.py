@@ -92,7 +92,7 @@ def test_pack_reads_layout():
     import opal_amd
     pr = opal_amd.PackedReads.from_sequences([b"ACGTACGTA", b"acgt", b"", b"TTTT", b"ACGN"])
     assert pr.len.tolist() == [9, 4 | 0x80000000, 0, 4, 4 | 0x80000000]
-    assert pr.off.tolist() == [0, 3, 7, 7, 8]
+    assert pr.off.tolist() == [0, 3, 7 * 4, 7 * 4, 8]            # packed: base offsets, raw: byte offsets
     assert pr.data[:3].tolist() == [0b11100100, 0b11100100, 0]
     assert bytes(pr.data[3:7]) == b"acgt" and pr.data[7] == 0xFF and bytes(pr.data[8:12]) == b"ACGN"
     codes = np.array([[0, 1, 2, 3, 0, 1, 2, 3, 0]], dtype=np.uint8)
