@@ -36,25 +36,35 @@ WORKLOADS = {
                         desc="1564 classes, 200bp fragments per GPU shard, numHash=1, -r, b=31"),
     "cfg4_numhash4": dict(K=1564, n=200_000, pattern="patterns_k64_t16_m4_s7.txt", bits=31, mode="predict",
                           desc="1564 classes, numHash=4 (P=5, F=1370), -r, b=31"),
-    "cfg5_emit": dict(K=0, n=4_000_000, pattern="patterns_k64_t16_m1_s7.txt", bits=31, mode="emit",
-                      desc="training-feature generation: emit hashed features of 200bp fragments, numHash=1, -r"),
+    "cfg5_emit": dict(K=1564, n=4_000_000, pattern="patterns_k64_t16_m1_s7.txt", bits=31, mode="emit",
+                      desc="training-feature generation: sample 200bp fragments from 1564 HBM-resident genomes (zero-copy views) "
+                           "and emit their hashed features, numHash=1, -r"),
+    "train_356sp": dict(K=356, n=200_000, pattern="patterns_k64_t16_m1_s7.txt", bits=31, mode="train",
+                        desc="native OAA learner: one pass over 200k labelled 200bp fragments, 356 classes, numHash=1, -r, b=31"),
+    "train_1564sp": dict(K=1564, n=50_000, pattern="patterns_k64_t16_m1_s7.txt", bits=31, mode="train",
+                         desc="native OAA learner: one pass over 50k labelled 200bp fragments, 1564 classes, numHash=1, -r, b=31"),
 }
 
 
-def make_fragments(rank, n, L, K):
-    """Synthetic genomes (uniform ACGT, PCG64 seed 1234) sampled with the CPython-exact sampler (seed 42+rank)
-    through the C-ABI, like `opal.py frag` would (reference opal.py:187-196)."""
+def make_genomes_and_draws(rank, n, L, K, glen):
+    """Synthetic genomes (uniform ACGT, PCG64 seed 1234) + n fragment draws (position, genome) from the CPython-exact
+    sampler (seed 42+rank) through the C-ABI, like `opal.py frag` (reference opal.py:187-196), in shuffled order
+    (reads arrive in no particular order; opal.py:363 shuffles training batches with the same stream)."""
     import opal_amd
     n_genomes = max(K, 8)
-    glen = 1_000_000   # low coverage (a metagenomic sample covers its genomes thinly): rows are not re-used
     g = np.random.Generator(np.random.PCG64(1234)).integers(0, 4, size=(n_genomes, glen), dtype=np.uint8)
     cov = (n * L) / float(n_genomes * glen) * 1.02 + 1e-4
     rng = opal_amd.Rng(42 + rank)
     pos, gen = rng.sample_positions([glen] * n_genomes, L, cov)
     assert len(pos) >= n, (len(pos), n)
-    # reads arrive in no particular order: shuffle with the same stream (as opal.py:363 does for training batches)
     sel = rng.shuffle_perm(len(pos))[:n].astype(np.int64)
-    pos, gen = pos[sel].astype(np.int64), gen[sel].astype(np.int64)
+    return g, pos[sel].astype(np.int64), gen[sel].astype(np.int64)
+
+
+def make_fragments(rank, n, L, K):
+    """Explicit fragment codes [n, L] cut from low-coverage genomes (a metagenomic sample covers its genomes thinly, so
+    weight rows are not re-used between fragments)."""
+    g, pos, gen = make_genomes_and_draws(rank, n, L, K, 1_000_000)
     codes = np.empty((n, L), dtype=np.uint8)
     step = 100_000
     ar = np.arange(L, dtype=np.int64)
@@ -67,6 +77,9 @@ def make_fragments(rank, n, L, K):
 def algorithmic_bytes_per_fragment(L, F, K, mode):
     if mode == "emit":
         return math.ceil(L / 4) + 4 * F                      # 2-bit read + one u32 per feature
+    if mode == "train":
+        # sweep 1 reads w rows; sweep 2 reads+writes G rows; sweep 3 reads G rows, reads+writes w rows (opal_train.hip)
+        return math.ceil(L / 4) + 6 * 4 * K * (F + 1) + 4
     return math.ceil(L / 4) + 4 * K * (F + 1) + 4             # 2-bit read + (F+1) rows of K floats + class id
 
 
@@ -121,10 +134,25 @@ def main():
         w.normal_(0.0, 0.05, generator=gen)           # fp32 N(0, 0.05^2) dense table, same on every rank
         eng.load_weights(w, K, bits)
         eng.set_vw_options()                            # VW defaults: --hash strings, constant feature, clip to [-1,1]
-    codes = make_fragments(rank, n, L, max(K, 1))
-    batch = eng.upload(opal_amd.PackedReads.from_codes(codes))
+    labels = None
+    if mode == "predict":
+        codes = make_fragments(rank, n, L, max(K, 1))
+        batch = eng.upload(opal_amd.PackedReads.from_codes(codes))
+    else:
+        # genomes packed once and resident in HBM; a batch is 12 bytes of (offset, length) per fragment
+        g, gpos, ggen = make_genomes_and_draws(rank, n, L, max(K, 1), 200_000)
+        gs = opal_amd.GenomeSet(eng, opal_amd.PackedReads.from_codes(g))
+        batch = gs.fragments(gpos, ggen, L)
+        codes = None
+        labels = torch.from_numpy((ggen % K + 1).astype(np.int32)).to(dev)
     out_class = torch.empty(n, dtype=torch.int32, device=dev)
-    if mode == "emit":
+    if mode == "train":
+        eng.set_vw_options()
+        eng.train_begin(K, bits)
+
+        def step():
+            eng.train_batch(batch, labels, True, eta=0.5)
+    elif mode == "emit":
         offsets = eng.feature_offsets(batch, True)
         total = int(offsets[-1].item())
         out_idx = torch.empty(total, dtype=torch.int32, device=dev)
@@ -172,17 +200,19 @@ def main():
         res = {
             "metric": "fragments/sec", "value": frag_per_s, "unit": "fragments/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if mode == "predict" else "u32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u32" if mode == "emit" else "f32", "data": "synthetic",
             "config": {"workload": args.workload, "desc": wl["desc"], "classes": K, "fragments_per_gpu": n, "frag_len": L,
                        "kmer": k, "row_weight": 16, "patterns": P, "reverse_complement": True, "bits": bits,
                        "features_per_fragment": F, "parallelism": "fragment-sharded x%d, replicated table, no collective" % world},
             "hashes_per_s": frag_per_s * F,
-            "kernel": eng.predict_kernel_name() if mode == "predict" else "emit_idx_kernel",
+            "kernel": {"predict": eng.predict_kernel_name(), "emit": "emit_idx_kernel", "train": "train_kernel"}[mode],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": abytes, "kernel_ms": kern_ms},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        import shutil
+        res["vw_binary_on_box"] = shutil.which("vw")       # time a real vw if one exists (never seen so far)
+        if world == 1 and not args.no_cpu_baseline and codes is not None:
             res["cpu_baseline"] = cpu_baseline(codes, pos, k, w, K, bits, mode, min(args.cpu_sample, n), out_class, eng, batch)
         print(json.dumps(res), flush=True)
     if dist:

@@ -64,6 +64,37 @@ __device__ __forceinline__ void load_tile(uint8_t *sq, const uint8_t *src, uint3
     }
 }
 
+// Fast staging of a 2-bit packed fragment: each lane expands 4 consecutive bases (one output dword) with two byte
+// loads, a funnel shift and v_perm_b32 lookups into "ACGT" (forward) or "TGCA" (complement, bases taken in
+// descending order for the reverse strand).  abs0 = absolute base offset of the fragment inside `reads`.
+// Bytes of sq at positions >= len receive don't-care values (no window reads them).
+__device__ __forceinline__ void load_strand_packed(uint8_t *sq, const uint8_t *__restrict__ reads, uint64_t reads_bytes,
+                                                   uint64_t abs0, uint32_t len, int strand, int lane)
+{
+    uint32_t *sq4 = reinterpret_cast<uint32_t *>(sq);
+    const int64_t last_byte = (int64_t)reads_bytes - 1;
+    for (uint32_t i = lane; i < (len + 3u) / 4u; i += WAVE) {
+        // forward: bases 4i..4i+3 ascending; reverse: output chars 4i..4i+3 = comp of bases len-1-4i .. len-4-4i
+        const int64_t a = strand ? (int64_t)abs0 + (int64_t)len - 4 - 4 * (int64_t)i : (int64_t)abs0 + 4 * (int64_t)i;
+        const int64_t bi = a >> 2;
+        const uint32_t sh = (uint32_t)(a & 3) * 2u;
+        const uint32_t lo = reads[min(max(bi, (int64_t)0), last_byte)];
+        const uint32_t hi = reads[min(max(bi + 1, (int64_t)0), last_byte)];
+        const uint32_t x = ((lo | (hi << 8)) >> sh) & 0xffu;         // 4 codes, base a in bits 1:0
+        const uint32_t y = (x & 0x33u) * 0x1001u & 0x00030003u;       // codes 0,2 -> bytes 0,2
+        const uint32_t z = ((x >> 2) & 0x33u) * 0x1001u & 0x00030003u; // codes 1,3 -> bytes 0,2
+        uint32_t sel = y | (z << 8);                                   // selector byte j = code of base a+j
+        uint32_t chars;
+        if (strand) {
+            sel = __builtin_amdgcn_perm(0u, sel, 0x00010203u);         // reverse the 4 bases
+            chars = __builtin_amdgcn_perm(0u, 0x41434754u, sel);       // "TGCA"[code] = complement
+        } else {
+            chars = __builtin_amdgcn_perm(0u, 0x54474341u, sel);       // "ACGT"[code]
+        }
+        sq4[i] = chars;
+    }
+}
+
 // Resolves fragment `frag` of a batch: raw fragments are addressed in BYTES, packed ones in BASES (so that a packed
 // fragment can alias any window of a packed genome).  A fragment that would reach outside the buffer gets len 0.
 struct FragRef {
@@ -99,7 +130,10 @@ __device__ __forceinline__ uint32_t mm_h(uint32_t h, uint32_t k1)
 {
     h ^= mm_k(k1);
     h = rotl32(h, 13);
-    return h * 5u + 0xe6546b64u;
+    // h*5 + c as shift-add: keeps the quarter-rate integer multiplier for the two products that need it
+    uint32_t h5;
+    asm("v_lshl_add_u32 %0, %1, 2, %1" : "=v"(h5) : "v"(h));
+    return h5 + 0xe6546b64u;
 }
 __device__ __forceinline__ uint32_t mm_fin(uint32_t h, uint32_t len)
 {
@@ -174,33 +208,63 @@ __device__ __forceinline__ void walk_fragment(const Batch &B, const Geom &G, uin
     const bool fast16 = (t == 16) && (P <= 10) && !raw;
     const bool digit_rule = raw && !G.hash_all;
     uint32_t fill = 0;
+    const uint32_t S = G.reverse ? 2u : 1u;
+    // hashes `cnt` windows whose LDS start is base_of(local index) and appends them at hb[fill + local*P + p]
+    auto hash_windows = [&](uint32_t cnt, auto &&base_of) {
+        for (int p = 0; p < P; p++) {
+            const uint8_t *pp = G.pos + p * t;
+            for (uint32_t wl = lane; wl < cnt; wl += WAVE) {
+                const uint8_t *wb = sq + base_of(wl);
+                uint32_t h;
+                if (fast16) h = hash_name_fast<16>(wb, pp, p) & mask;
+                else h = hash_name_generic(wb, pp, t, p, digit_rule, mask);
+                hb[fill + wl * (uint32_t)P + (uint32_t)p] = h;
+            }
+        }
+        // wave-private LDS: every lane's ds_write retires before the next ds_read issues (same wave, in-order
+        // LDS queue); the fences only stop the compiler from reordering.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        fill += cnt * (uint32_t)P;
+    };
     if (len >= (uint32_t)k) {
         const uint32_t W = len - (uint32_t)k + 1u;
-        const uint32_t tw_seq = (uint32_t)(SEQB - k + 1);
-        for (int s = 0; s < (G.reverse ? 2 : 1); s++) {
-            uint32_t w0 = 0;
-            while (w0 < W) {
+        constexpr uint32_t LP = SEQB / 2;
+        if (len <= LP) {
+            // whole fragment resident: both strands staged once, windows of the two strands share one flat index
+            // (fewer partially filled 64-lane steps: 274 windows -> 5 steps instead of 2 x 3)
+            if (raw) {
+                load_tile(sq, src, len, raw, fr.shift, 0, 0, len, lane);
+                if (S == 2) load_tile(sq + LP, src, len, raw, fr.shift, 1, 0, len, lane);
+            } else {
+                load_strand_packed(sq, B.reads, B.reads_bytes, B.off[frag], len, 0, lane);
+                if (S == 2) load_strand_packed(sq + LP, B.reads, B.reads_bytes, B.off[frag], len, 1, lane);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t U = S * W;
+            uint32_t u0 = 0;
+            while (u0 < U) {
                 uint32_t room = (HB - fill) / (uint32_t)P;
-                if (room < min(W - w0, (uint32_t)WAVE)) { flush(fill); fill = 0; room = HB / (uint32_t)P; }
-                const uint32_t tw = min(min(W - w0, tw_seq), room);
-                load_tile(sq, src, len, raw, fr.shift, s, w0, tw + (uint32_t)k - 1u, lane);
-                // wave-private LDS: every lane's ds_write retires before the next ds_read issues (same wave,
-                // in-order LDS queue); the fence only stops the compiler from reordering.
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                for (int p = 0; p < P; p++) {
-                    const uint8_t *pp = G.pos + p * t;
-                    for (uint32_t wl = lane; wl < tw; wl += WAVE) {
-                        uint32_t h;
-                        if (fast16) h = hash_name_fast<16>(sq + wl, pp, p) & mask;
-                        else h = hash_name_generic(sq + wl, pp, t, p, digit_rule, mask);
-                        hb[fill + wl * (uint32_t)P + (uint32_t)p] = h;
-                    }
+                if (room < min(U - u0, (uint32_t)WAVE)) { flush(fill); fill = 0; room = HB / (uint32_t)P; }
+                const uint32_t tu = min(U - u0, room);
+                hash_windows(tu, [&](uint32_t ul) { const uint32_t u = u0 + ul; return u < W ? u : LP + (u - W); });
+                u0 += tu;
+            }
+        } else {
+            const uint32_t tw_seq = (uint32_t)(SEQB - k + 1);
+            for (uint32_t s = 0; s < S; s++) {
+                uint32_t w0 = 0;
+                while (w0 < W) {
+                    uint32_t room = (HB - fill) / (uint32_t)P;
+                    if (room < min(W - w0, (uint32_t)WAVE)) { flush(fill); fill = 0; room = HB / (uint32_t)P; }
+                    const uint32_t tw = min(min(W - w0, tw_seq), room);
+                    load_tile(sq, src, len, raw, fr.shift, (int)s, w0, tw + (uint32_t)k - 1u, lane);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    hash_windows(tw, [&](uint32_t wl) { return wl; });
+                    w0 += tw;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                fill += tw * (uint32_t)P;
-                w0 += tw;
             }
         }
     }

@@ -38,7 +38,14 @@ __global__ __launch_bounds__(BLOCK) void emit_idx_kernel(Batch B, Geom G, uint32
         uint32_t *dst = out_idx + out_off[frag];
         uint32_t *hb = s_hb[wv];
         walk_fragment(B, G, frag, mask, false, 0u, s_seq[wv], hb, lane, [&](uint32_t cnt) {
-            for (uint32_t i = lane; i < cnt; i += WAVE) dst[i] = hb[i];
+            if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {   // wave-uniform: 16-byte stores, then the tail
+                const uint32_t n4 = cnt / 4u;
+                for (uint32_t i = lane; i < n4; i += WAVE)
+                    reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(hb)[i];
+                for (uint32_t i = n4 * 4u + lane; i < cnt; i += WAVE) dst[i] = hb[i];
+            } else {
+                for (uint32_t i = lane; i < cnt; i += WAVE) dst[i] = hb[i];
+            }
             dst += cnt;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
