@@ -150,6 +150,13 @@ int opal_get_weights(opal_ctx *ctx, float *dst, int dst_is_device);
 /* Loads a model stored as nnz (slot index, weight) pairs (host arrays); all other slots are 0.                */
 int opal_load_weights_sparse(opal_ctx *ctx, const uint32_t *idx, const float *val, uint64_t nnz, int K, int bits);
 
+/* Evaluation counts.  Replaces the string compare + groupby of opal.evaluate_predictions (opal.py:111-131):
+ * d_total[c] = number of fragments whose reference class is c, d_correct[c] = those predicted as c.
+ * d_pred/d_ref: dense class ids in [0, n_classes) (ref) / any int (pred); both outputs are zeroed by the call.
+ * micro = sum(correct)/n, per-class accuracy = correct/total -> macro (mean), median.                         */
+int opal_eval_counts(opal_ctx *ctx, const int32_t *d_pred, const int32_t *d_ref, uint64_t n, uint32_t n_classes,
+                     uint64_t *d_correct, uint64_t *d_total);
+
 /* Name of the scoring-kernel variant opal_predict would launch for the current K (for profiles/bench).   */
 const char *opal_predict_kernel_name(opal_ctx *ctx);
 

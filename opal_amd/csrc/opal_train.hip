@@ -359,3 +359,62 @@ extern "C" int opal_load_weights_sparse(opal_ctx *ctx, const uint32_t *idx, cons
     OPAL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return OPAL_OK;
 }
+
+// ------------------------------------------------------------------------------------------ evaluation counts
+// Replaces the per-line string compare + pandas groupby of opal.evaluate_predictions (reference opal.py:111-131):
+// per reference class, how many fragments there are and how many were predicted correctly.  Classes are dense
+// integer ids (the host maps taxid strings through vw-dico.txt, reference opal.py:76-88).  Block-private LDS
+// histograms, one global atomic per non-empty bucket per block.
+namespace {
+constexpr int EVAL_LDS_CLASSES = 8192;
+__global__ __launch_bounds__(256) void eval_counts_kernel(const int32_t *__restrict__ pred, const int32_t *__restrict__ ref,
+                                                           uint64_t n, uint32_t n_classes,
+                                                           unsigned long long *__restrict__ correct,
+                                                           unsigned long long *__restrict__ total)
+{
+    __shared__ uint32_t s_tot[EVAL_LDS_CLASSES];
+    __shared__ uint32_t s_cor[EVAL_LDS_CLASSES];
+    const bool use_lds = n_classes <= EVAL_LDS_CLASSES;
+    if (use_lds) {
+        for (uint32_t i = threadIdx.x; i < n_classes; i += blockDim.x) { s_tot[i] = 0; s_cor[i] = 0; }
+        __syncthreads();
+    }
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t r = (uint32_t)ref[i];
+        if (r >= n_classes) continue;                 // host guarantees 0 <= ref < n_classes; never index outside
+        const bool ok = pred[i] == ref[i];
+        if (use_lds) {
+            atomicAdd(&s_tot[r], 1u);
+            if (ok) atomicAdd(&s_cor[r], 1u);
+        } else {
+            atomicAdd(&total[r], 1ull);
+            if (ok) atomicAdd(&correct[r], 1ull);
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n_classes; i += blockDim.x) {
+            if (s_tot[i]) atomicAdd(&total[i], (unsigned long long)s_tot[i]);
+            if (s_cor[i]) atomicAdd(&correct[i], (unsigned long long)s_cor[i]);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int opal_eval_counts(opal_ctx *ctx, const int32_t *d_pred, const int32_t *d_ref, uint64_t n, uint32_t n_classes,
+                                uint64_t *d_correct, uint64_t *d_total)
+{
+    if (!ctx) return opal::fail(nullptr, OPAL_EINVAL, "opal_eval_counts: null ctx");
+    if (n_classes == 0 || n_classes > (1u << 24)) return opal::fail(ctx, OPAL_EINVAL, "opal_eval_counts: need 1 <= n_classes <= 2^24");
+    if (!d_correct || !d_total || (n && (!d_pred || !d_ref))) return opal::fail(ctx, OPAL_EINVAL, "opal_eval_counts: null pointer");
+    OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    OPAL_HIP_CHECK(ctx, hipMemsetAsync(d_correct, 0, (size_t)n_classes * sizeof(uint64_t), ctx->stream));
+    OPAL_HIP_CHECK(ctx, hipMemsetAsync(d_total, 0, (size_t)n_classes * sizeof(uint64_t), ctx->stream));
+    if (n == 0) return OPAL_OK;
+    const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, (uint64_t)ctx->num_cus * 4));
+    hipLaunchKernelGGL(eval_counts_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_pred, d_ref, n, n_classes,
+                       (unsigned long long *)d_correct, (unsigned long long *)d_total);
+    OPAL_HIP_CHECK(ctx, hipGetLastError());
+    return OPAL_OK;
+}

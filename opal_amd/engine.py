@@ -287,3 +287,17 @@ class Engine:
         assert idx.size == val.size
         check(lib().opal_load_weights_sparse(self._h, idx.ctypes.data, val.ctypes.data, idx.size, K, bits), self._h)
         self.K, self.bits = K, bits
+
+    # ------------------------------------------------------------------ evaluation (reference opal.py:111-131)
+    def eval_counts(self, pred, ref, n_classes: int):
+        """pred, ref: int32 class ids (numpy or cuda tensors), ref in [0, n_classes). Returns (correct, total) numpy uint64."""
+        t = self.torch
+        if isinstance(pred, np.ndarray):
+            pred = t.from_numpy(np.ascontiguousarray(pred, dtype=np.int32)).to(self.device)
+        if isinstance(ref, np.ndarray):
+            ref = t.from_numpy(np.ascontiguousarray(ref, dtype=np.int32)).to(self.device)
+        n = min(pred.numel(), ref.numel())
+        cor = t.empty(n_classes, dtype=t.int64, device=self.device)
+        tot = t.empty(n_classes, dtype=t.int64, device=self.device)
+        check(lib().opal_eval_counts(self._h, pred.data_ptr(), ref.data_ptr(), n, n_classes, cor.data_ptr(), tot.data_ptr()), self._h)
+        return cor.cpu().numpy().view(np.uint64), tot.cpu().numpy().view(np.uint64)

@@ -17,7 +17,7 @@ import numpy as np
 MAGIC = b"OPALHIP1"
 _HDR = struct.Struct("<8sIIIIffQII")
 
-__all__ = ["save_model", "load_model", "read_header"]
+__all__ = ["save_model", "load_model", "read_header", "import_vw_readable_model"]
 
 
 def _nonzero_chunks(w, chunk=1 << 27):
@@ -88,3 +88,42 @@ def load_model(path, engine):
             engine.load_weights_sparse(idx, val, h["K"], h["bits"])
     engine.set_vw_options(h["hash_all"], h["add_constant"], h["clip"], h["min_label"], h["max_label"])
     return h
+
+
+def import_vw_readable_model(path):
+    """Best-effort reader of a VW `--readable_model` text dump.  UNVERIFIED against a real vw
+    (none exists here: parity unpinned); follows the published VW 8.x layout: header lines `key:value` (`bits:`,
+    `Min label:`, `Max label:`, `options: ... --oaa K ...`), a line `:<n>` that ends the header, then one
+    `slot:weight[ adaptive normalized]` line per non-zero weight, slot = (h*K + c) mod 2^bits.
+    Returns dict(idx uint32[], val float32[], K, bits, min_label, max_label)."""
+    import re
+    bits = K = None
+    minl, maxl = -1.0, 1.0
+    idx, val = [], []
+    in_weights = False
+    with open(path, "r", errors="replace") as f:
+        for line in f:
+            line = line.strip()
+            if not in_weights:
+                low = line.lower()
+                if low.startswith("bits:"):
+                    bits = int(line.split(":", 1)[1])
+                elif low.startswith("min label:"):
+                    minl = float(line.split(":", 1)[1])
+                elif low.startswith("max label:"):
+                    maxl = float(line.split(":", 1)[1])
+                elif low.startswith("options:"):
+                    m = re.search(r"--oaa[ =](\d+)", line)
+                    if m:
+                        K = int(m.group(1))
+                elif re.fullmatch(r":\d+", line):
+                    in_weights = True
+                continue
+            m = re.match(r"(\d+):(\S+)", line)
+            if m:
+                idx.append(int(m.group(1)))
+                val.append(float(m.group(2)))
+    if bits is None or K is None:
+        raise RuntimeError("%s: not a VW readable model with `bits:` and `--oaa K`" % path)
+    return dict(idx=np.array(idx, dtype=np.uint32), val=np.array(val, dtype=np.float32), K=K, bits=bits,
+                min_label=minl, max_label=maxl)

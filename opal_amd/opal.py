@@ -98,6 +98,29 @@ def evaluate_predictions(reffile, predfile):
     return micro, macro, median
 
 
+def evaluate_predictions_gpu(reffile, predfile, engine):
+    """Same numbers as evaluate_predictions, counted on the GPU (opal_eval_counts): taxid strings are mapped to dense
+    ids on the host, the per-class correct/total histograms come from the device."""
+    with open(predfile, "r") as fin:
+        pred = fin.read().splitlines()
+    with open(reffile, "r") as fin:
+        ref = fin.read().splitlines()
+    n = min(len(pred), len(ref))
+    ids = {}
+    r = np.fromiter((ids.setdefault(x, len(ids)) for x in ref[:n]), dtype=np.int32, count=n)
+    nref = len(ids)
+    p = np.fromiter((ids.get(x, -1) for x in pred[:n]), dtype=np.int32, count=n)
+    cor, tot = engine.eval_counts(p, r, max(nref, 1))
+    species = cor[:nref].astype(np.float64) / np.maximum(tot[:nref], 1)
+    micro = float(cor.sum()) / max(n, 1)
+    macro, median = float(np.mean(species)), float(np.median(species))
+    print("micro = {:.4f}".format(micro))
+    print("macro = {:.4f}".format(macro))
+    print("median = {:.4f}".format(median))
+    sys.stdout.flush()
+    return micro, macro, median
+
+
 def _dist():
     """torch.distributed when launched with WORLD_SIZE>1 (one rank per GPU), else None."""
     if int(os.environ.get("WORLD_SIZE", "1")) <= 1:

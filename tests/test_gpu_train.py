@@ -152,3 +152,43 @@ def test_cli_simulate_pipeline(amd, tmp_path, capsys):
     # eval sub-command on the same files prints the same numbers
     opal.main(["eval", str(out / "1frag" / "test.fragments.taxid"), str(out / "3predict" / "test.fragments-db.preds.taxid")])
     assert "micro = %.4f" % micro in capsys.readouterr().out
+
+
+def test_gpu_eval_counts_match_host(amd, oracle, tmp_path, capsys):
+    from opal_amd import opal
+    rng = np.random.default_rng(1)
+    n, C = 50_000, 37
+    ref = rng.integers(0, C, size=n)
+    pred = np.where(rng.random(n) < 0.8, ref, rng.integers(0, C + 3, size=n))
+    names = ["tax%d" % i for i in range(C + 3)]
+    rf, pf = tmp_path / "ref.taxid", tmp_path / "pred.taxid"
+    rf.write_text("".join(names[i] + "\n" for i in ref))
+    pf.write_text("".join(names[i] + "\n" for i in pred))
+    eng = amd.Engine(0)
+    got = opal.evaluate_predictions_gpu(str(rf), str(pf), eng)
+    host = opal.evaluate_predictions(str(rf), str(pf))
+    want = oracle.evaluate([names[i] for i in ref], [names[i] for i in pred])
+    assert np.allclose(got, want, atol=1e-12) and np.allclose(host, want, atol=1e-12)
+    # many classes: the global-atomic path
+    C2 = 20_000
+    r2 = rng.integers(0, C2, size=n).astype(np.int32)
+    p2 = np.where(rng.random(n) < 0.5, r2, 0).astype(np.int32)
+    cor, tot = eng.eval_counts(p2, r2, C2)
+    assert np.array_equal(tot, np.bincount(r2, minlength=C2).astype(np.uint64))
+    assert np.array_equal(cor, np.bincount(r2[p2 == r2], minlength=C2).astype(np.uint64))
+    eng.close()
+
+
+def test_vw_readable_model_import(amd, tmp_path):
+    """Best-effort text importer (layout from VW 8.x documentation; unverified against a real vw)."""
+    from opal_amd import model as model_io
+    p = tmp_path / "m.txt"
+    p.write_text("Version 8.6.1\nId \nMin label:-1\nMax label:1\nbits:12\nlda:0\n0 ngram:\n0 skip:\n"
+                 "options: --oaa 3 --random_seed 420\nChecksum: 1\n:0\n5:0.25\n17:-1.5 0.3 1\n4095:2\n")
+    m = model_io.import_vw_readable_model(str(p))
+    assert (m["K"], m["bits"]) == (3, 12) and m["idx"].tolist() == [5, 17, 4095] and m["val"].tolist() == [0.25, -1.5, 2.0]
+    eng = amd.Engine(0)
+    eng.load_weights_sparse(m["idx"], m["val"], m["K"], m["bits"])
+    w = eng.get_weights(to_host=True)
+    assert w[5] == 0.25 and w[17] == -1.5 and w[4095] == 2.0 and np.count_nonzero(w) == 3
+    eng.close()
