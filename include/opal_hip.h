@@ -150,6 +150,17 @@ int opal_get_weights(opal_ctx *ctx, float *dst, int dst_is_device);
 /* Loads a model stored as nnz (slot index, weight) pairs (host arrays); all other slots are 0.                */
 int opal_load_weights_sparse(opal_ctx *ctx, const uint32_t *idx, const float *val, uint64_t nnz, int K, int bits);
 
+/* GPU-side FASTA ingest.  Replaces fasta_functions.fasta_reader over open(path,'r')
+ * (util/fasta_functions.py:9-43, universal newlines, '+' mutes up to the next '>', text before the first '>' is
+ * dropped, an empty last record is dropped) followed by opal_pack_reads, for a whole file whose bytes are already
+ * in HBM: d_text[nbytes] -> fragment batch (d_reads_out, d_frag_off, d_frag_len) in record order.
+ * d_reads_out needs room for reads_cap >= nbytes bytes, d_frag_off/d_frag_len for max_records entries
+ * (max_records >= number of '>' in the text, or 1).  Record names are not produced.  Synchronises the stream and
+ * returns the record count and the bytes written through the two host pointers.                              */
+int opal_ingest_fasta(opal_ctx *ctx, const uint8_t *d_text, uint64_t nbytes, uint8_t *d_reads_out, uint64_t reads_cap,
+                      uint64_t *d_frag_off, uint32_t *d_frag_len, uint64_t max_records, uint64_t *n_records_out,
+                      uint64_t *reads_bytes_out);
+
 /* Evaluation counts.  Replaces the string compare + groupby of opal.evaluate_predictions (opal.py:111-131):
  * d_total[c] = number of fragments whose reference class is c, d_correct[c] = those predicted as c.
  * d_pred/d_ref: dense class ids in [0, n_classes) (ref) / any int (pred); both outputs are zeroed by the call.

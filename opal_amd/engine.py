@@ -301,3 +301,27 @@ class Engine:
         tot = t.empty(n_classes, dtype=t.int64, device=self.device)
         check(lib().opal_eval_counts(self._h, pred.data_ptr(), ref.data_ptr(), n, n_classes, cor.data_ptr(), tot.data_ptr()), self._h)
         return cor.cpu().numpy().view(np.uint64), tot.cpu().numpy().view(np.uint64)
+
+    # ------------------------------------------------------------------ GPU-side FASTA ingest
+    def ingest_fasta(self, text) -> DeviceBatch:
+        """text: bytes / numpy uint8 / path of a FASTA file.  The file's bytes go to HBM as they are; record splitting,
+        newline stripping, the '+' rule and 2-bit packing happen on the device (opal_ingest_fasta)."""
+        t = self.torch
+        if isinstance(text, str):
+            arr = np.fromfile(text, dtype=np.uint8)
+        elif isinstance(text, (bytes, bytearray)):
+            arr = np.frombuffer(bytes(text), dtype=np.uint8)
+        else:
+            arr = np.ascontiguousarray(text, dtype=np.uint8)
+        n = int(arr.size)
+        if n == 0:
+            return self.upload(PackedReads.from_sequences([]))
+        d_text = t.from_numpy(arr.copy() if not arr.flags.writeable else arr).to(self.device)
+        max_rec = int((d_text == 62).sum().item()) + 1          # number of '>' bytes bounds the record count
+        reads = t.empty(n, dtype=t.uint8, device=self.device)
+        off = t.empty(max_rec, dtype=t.int64, device=self.device)
+        ln = t.empty(max_rec, dtype=t.int32, device=self.device)
+        nrec, nb = C.c_uint64(), C.c_uint64()
+        check(lib().opal_ingest_fasta(self._h, d_text.data_ptr(), n, reads.data_ptr(), n, off.data_ptr(), ln.data_ptr(), max_rec,
+                                      C.byref(nrec), C.byref(nb)), self._h)
+        return DeviceBatch(reads, off, ln, int(nrec.value), max(int(nb.value), 1))

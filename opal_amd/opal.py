@@ -274,20 +274,22 @@ def predict(model_dir, test_dir, predict_dir, args, engine=None, chunk=2_000_000
     eng = engine or Engine(local)
     eng.set_patterns(pos, kmer)
     hdr = model_io.load_model(model, eng)
-    with open(fasta, "r", encoding="latin-1") as f:
-        seqs = [s.encode("latin-1") for _, s in fasta_reader(f)]
-    lo, hi = shard_range(len(seqs), rank, world)            # contiguous fragment range per rank
-    out = []
-    for c0 in range(lo, hi, chunk):
-        part = seqs[c0:min(hi, c0 + chunk)]
-        cls, _ = eng.predict(eng.upload(PackedReads.from_sequences(part)), reverse)
-        out.append(cls.cpu().numpy())
-    local_cls = np.concatenate(out) if out else np.zeros(0, dtype=np.int32)
+    # the file's bytes go to HBM as they are; records are split and 2-bit packed on the device (opal_ingest_fasta)
+    whole = eng.ingest_fasta(fasta)
+    n_frag = whole.n
+    lo, hi = shard_range(n_frag, rank, world)                # contiguous fragment range per rank
+    if hi > lo:
+        from .engine import DeviceBatch
+        mine = DeviceBatch(whole.data, whole.off[lo:hi], whole.len[lo:hi], hi - lo, whole.nbytes)
+        cls, _ = eng.predict(mine, reverse)
+        local_cls = cls.cpu().numpy()
+    else:
+        local_cls = np.zeros(0, dtype=np.int32)
     full = gather_in_rank_order(local_cls, dist)
     if rank == 0:
         with open(prefix + "_vwps.log", "w") as log:
             log.write("opal_amd scorer: %d fragments, oaa=%d bits=%d, kernel %s, %d rank(s)\n" % (
-                len(seqs), hdr["K"], hdr["bits"], eng.predict_kernel_name(), world))
+                n_frag, hdr["K"], hdr["bits"], eng.predict_kernel_name(), world))
         with open(prediction_file, "w") as f:                # what `vw -p` writes: one class id per line
             f.write("".join("%d\n" % c for c in full.tolist()))
         vw_class_to_taxid(prediction_file, dico, prefix + '.preds.taxid')

@@ -258,3 +258,57 @@ def test_zero_copy_fragments_from_resident_genomes(amd, eng, oracle, golden_dir)
     bad = gs.fragments(np.array([4000]), np.array([3]), 2000)
     idx2, off2 = eng.features(bad, True, 31)
     assert off2.cpu().numpy().tolist()[0] == 0
+
+
+def _check_ingest(amd, eng, oracle, text: bytes):
+    recs = oracle.fasta_read(text, universal_newlines=True)
+    want = amd.PackedReads.from_sequences([sq for _, sq in recs])
+    b = eng.ingest_fasta(text)
+    assert b.n == len(recs), (b.n, len(recs))
+    if b.n == 0:
+        return
+    assert np.array_equal(b.len.cpu().numpy()[:b.n].view(np.uint32), want.len)
+    assert np.array_equal(b.off.cpu().numpy()[:b.n].view(np.uint64), want.off)
+    nb = int(want.data.size) if want.len.size and (want.len & 0x7fffffff).sum() else 0
+    assert np.array_equal(b.data.cpu().numpy()[:nb], want.data[:nb])
+
+
+def test_gpu_fasta_ingest_matches_reference_reader(amd, eng, oracle, golden_dir):
+    """opal_ingest_fasta == fasta_reader over open(path,'r') + opal_pack_reads, on the golden FASTA texts (the lines
+    the reference built from them are pinned in skm.json) and on adversarial synthetic files."""
+    for c in _load(golden_dir, "skm.json"):
+        _check_ingest(amd, eng, oracle, c["fasta"].encode("latin-1"))
+    for txt, _ in _load(golden_dir, "primitives.json")["fasta_reader"]:
+        _check_ingest(amd, eng, oracle, txt.encode("latin-1"))
+    rng = np.random.default_rng(123)
+    pieces = [b"ACGT", b"acgtn", b"N", b"\n", b"\r\n", b"\r", b">", b">name x\n", b"+", b"+\n", b"\n+\n", b"\n>h\n", b" ", b"@r\n"]
+    for trial in range(60):
+        k = int(rng.integers(1, 60))
+        txt = b"".join(pieces[int(i)] * int(rng.integers(1, 4)) for i in rng.integers(0, len(pieces), size=k))
+        _check_ingest(amd, eng, oracle, txt)
+    # a file that spans many 4 KiB tiles, with records of all sizes, CRLF sections and FASTQ-style quality blocks
+    parts = []
+    for i in range(3000):
+        L = int(rng.integers(0, 700))
+        body = bytes(rng.choice(ACGT, size=L))
+        if i % 7 == 0:
+            body = body.lower()
+        width = int(rng.integers(20, 90))
+        nl = b"\r\n" if i % 5 == 0 else b"\n"
+        lines = nl.join(body[j:j + width] for j in range(0, L, width))
+        parts.append(b">rec%d desc" % i + nl + lines + nl)
+        if i % 11 == 0:
+            parts.append(b"+" + nl + b"I" * L + nl)
+    big = b"junk before the first header\n" + b"".join(parts)
+    assert len(big) > 200 * 4096
+    _check_ingest(amd, eng, oracle, big)
+    # end to end: predictions from the ingested batch equal predictions from host-parsed records
+    pos = _patterns(amd, golden_dir, "patterns_k64_t16_m1_s7.txt", 64)
+    eng.set_patterns(pos, 64)
+    K, bits = 24, 16
+    w = (rng.standard_normal(1 << bits) * 0.05).astype(np.float32)
+    eng.load_weights(w, K, bits)
+    seqs = [sq for _, sq in oracle.fasta_read(big)]
+    c1, _ = eng.predict(eng.ingest_fasta(big), True)
+    c2, _ = eng.predict(eng.upload(amd.PackedReads.from_sequences(seqs)), True)
+    assert np.array_equal(c1.cpu().numpy(), c2.cpu().numpy())
