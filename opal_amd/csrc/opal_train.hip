@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <string>
 
 #include "opal_device.h"
@@ -37,9 +38,14 @@ __device__ __forceinline__ void vstore(float *p, const float (&o)[VEC])
     else *p = o[0];
 }
 
+// 1/sqrt(x) as one v_rsq_f32 (1 ulp) instead of a correctly rounded sqrt + divide (~60 instructions per element):
+// the per-weight learning rate does not need the last bit, and the sweeps were ALU-bound without it.
+__device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+
 struct TrainArgs {
     float eta, l1, l2, min_label, max_label;
     int sequential;
+    int phases;   // diagnostic: bit0 = run sweep 2, bit1 = run sweep 3 (always 3 outside profiling experiments)
 };
 
 template <int VEC, int NV, int U>
@@ -105,31 +111,85 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
                     ppu[j][e] = 0.0f;
                 }
             const float s = ta.eta / sqrtf((float)nfeat);
+            // Sweeps 2 and 3 keep U2 rows in flight when the rows of a group cannot touch the same slot (VW's layout
+            // lets rows overlap: |row_a - row_b| mod 2^b < K); otherwise, and for the constant row in concurrent
+            // mode (atomics), the group is processed row by row so that the result equals the sequential rule.
+            constexpr int U2 = (NV <= 2) ? 4 : (NV == 4 ? 2 : 1);
+            const uint32_t thr = (mask - Ku + 1u) & mask;                       // 2^b - K
+            const bool tiny = (uint64_t)Ku * 2ull > (uint64_t)mask + 1ull;      // every pair of rows overlaps
+            auto independent = [&](const uint32_t (&row)[U2], const uint32_t (&idx)[U2]) -> bool {
+                bool ok = !tiny;
+#pragma unroll
+                for (int x = 0; x < U2; x++) {
+                    ok = ok && (ta.sequential || idx[x] != const_idx);
+#pragma unroll
+                    for (int y = x + 1; y < U2; y++) {
+                        const uint32_t d = (row[x] - row[y]) & mask;
+                        ok = ok && d >= Ku && d <= thr;
+                    }
+                }
+                return ok;
+            };
             // ---- sweep 2: adaptive accumulators + prediction-per-update
+            auto adapt_one = [&](uint32_t idx) {
+                const uint32_t row = (idx * Ku) & mask;
+                const bool shared_row = (idx == const_idx) && !ta.sequential;
+#pragma unroll
+                for (int j = 0; j < NV; j++) {
+                    if (cls[j] < Ku) {
+                        float *gp = g2 + (size_t)((row + cls[j]) & mask);
+                        float gv[VEC];
+                        if (shared_row) {   // every example touches the constant row: returning atomics, no lost adds
+#pragma unroll
+                            for (int e = 0; e < VEC; e++) gv[e] = atomicAdd(gp + e, gsq[j][e]) + gsq[j][e];
+                        } else {
+                            vload<VEC>(gp, gv);
+#pragma unroll
+                            for (int e = 0; e < VEC; e++) gv[e] += gsq[j][e];
+                            vstore<VEC>(gp, gv);
+                        }
+#pragma unroll
+                        for (int e = 0; e < VEC; e++) ppu[j][e] += (gv[e] > 0.0f) ? rsq(gv[e]) : 0.0f;
+                    }
+                }
+            };
+            if (ta.phases & 1)
             walk_fragment(B, G, frag, mask, true, const_idx, s_seq[wv], hb, lane, [&](uint32_t cnt) {
-                for (uint32_t f = 0; f < cnt; f++) {
-                    const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)hb[f]);
-                    const uint32_t row = (idx * Ku) & mask;
-                    const bool shared_row = (idx == const_idx) && !ta.sequential;
+                uint32_t f = 0;
+                if constexpr (U2 > 1) {
+                    for (; f + U2 <= cnt; f += U2) {
+                        uint32_t idx[U2], row[U2];
 #pragma unroll
-                    for (int j = 0; j < NV; j++) {
-                        if (cls[j] < Ku) {
-                            float *gp = g2 + (size_t)((row + cls[j]) & mask);
-                            float gv[VEC];
-                            if (shared_row) {   // every example touches the constant row: returning atomics, no lost adds
+                        for (int u = 0; u < U2; u++) {
+                            idx[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)hb[f + u]);
+                            row[u] = (idx[u] * Ku) & mask;
+                        }
+                        if (independent(row, idx)) {
+                            float gv[U2][NV][VEC];
 #pragma unroll
-                                for (int e = 0; e < VEC; e++) gv[e] = atomicAdd(gp + e, gsq[j][e]) + gsq[j][e];
-                            } else {
-                                vload<VEC>(gp, gv);
+                            for (int u = 0; u < U2; u++)
 #pragma unroll
-                                for (int e = 0; e < VEC; e++) gv[e] += gsq[j][e];
-                                vstore<VEC>(gp, gv);
-                            }
+                                for (int j = 0; j < NV; j++) vload<VEC>(g2 + (size_t)((row[u] + loff[j]) & mask), gv[u][j]);
 #pragma unroll
-                            for (int e = 0; e < VEC; e++) ppu[j][e] += (gv[e] > 0.0f) ? 1.0f / sqrtf(gv[e]) : 0.0f;
+                            for (int u = 0; u < U2; u++)
+#pragma unroll
+                                for (int j = 0; j < NV; j++) {
+                                    if (cls[j] < Ku) {
+#pragma unroll
+                                        for (int e = 0; e < VEC; e++) {
+                                            gv[u][j][e] += gsq[j][e];
+                                            ppu[j][e] += (gv[u][j][e] > 0.0f) ? rsq(gv[u][j][e]) : 0.0f;
+                                        }
+                                        vstore<VEC>(g2 + (size_t)((row[u] + cls[j]) & mask), gv[u][j]);
+                                    }
+                                }
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < U2; u++) adapt_one(idx[u]);
                         }
                     }
                 }
+                for (; f < cnt; f++) adapt_one((uint32_t)__builtin_amdgcn_readfirstlane((int)hb[f]));
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             });
@@ -148,39 +208,79 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
             const float decay = 1.0f - s * ta.l2;
             const float shrink = s * ta.l1;
             const bool reg = (ta.l1 != 0.0f) || (ta.l2 != 0.0f);
-            walk_fragment(B, G, frag, mask, true, const_idx, s_seq[wv], hb, lane, [&](uint32_t cnt) {
-                for (uint32_t f = 0; f < cnt; f++) {
-                    const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)hb[f]);
-                    const uint32_t row = (idx * Ku) & mask;
-                    const bool shared_row = (idx == const_idx) && !ta.sequential;
+            auto finish_w = [&](float wold, float d) -> float {
+                float nw = wold + d;
+                if (reg) {
+                    nw *= decay;
+                    nw = nw > shrink ? nw - shrink : (nw < -shrink ? nw + shrink : 0.0f);
+                }
+                return nw;
+            };
+            auto update_one = [&](uint32_t idx) {
+                const uint32_t row = (idx * Ku) & mask;
+                const bool shared_row = (idx == const_idx) && !ta.sequential;
 #pragma unroll
-                    for (int j = 0; j < NV; j++) {
-                        if (cls[j] < Ku) {
-                            const size_t slot = (size_t)((row + cls[j]) & mask);
-                            float gv[VEC], d[VEC];
-                            vload<VEC>(g2 + slot, gv);
+                for (int j = 0; j < NV; j++) {
+                    if (cls[j] < Ku) {
+                        const size_t slot = (size_t)((row + cls[j]) & mask);
+                        float gv[VEC], d[VEC];
+                        vload<VEC>(g2 + slot, gv);
 #pragma unroll
-                            for (int e = 0; e < VEC; e++) d[e] = (gv[e] > 0.0f) ? upd[j][e] / sqrtf(gv[e]) : 0.0f;
-                            if (shared_row && !reg) {
+                        for (int e = 0; e < VEC; e++) d[e] = (gv[e] > 0.0f) ? upd[j][e] * rsq(gv[e]) : 0.0f;
+                        if (shared_row && !reg) {
 #pragma unroll
-                                for (int e = 0; e < VEC; e++) atomicAdd(w + slot + e, d[e]);
-                            } else {
-                                float wv4[VEC];
-                                vload<VEC>(w + slot, wv4);
+                            for (int e = 0; e < VEC; e++) atomicAdd(w + slot + e, d[e]);
+                        } else {
+                            float wv4[VEC];
+                            vload<VEC>(w + slot, wv4);
 #pragma unroll
-                                for (int e = 0; e < VEC; e++) {
-                                    float nw = wv4[e] + d[e];
-                                    if (reg) {
-                                        nw *= decay;
-                                        nw = nw > shrink ? nw - shrink : (nw < -shrink ? nw + shrink : 0.0f);
-                                    }
-                                    wv4[e] = nw;
-                                }
-                                vstore<VEC>(w + slot, wv4);
-                            }
+                            for (int e = 0; e < VEC; e++) wv4[e] = finish_w(wv4[e], d[e]);
+                            vstore<VEC>(w + slot, wv4);
                         }
                     }
                 }
+            };
+            if (ta.phases & 2)
+            walk_fragment(B, G, frag, mask, true, const_idx, s_seq[wv], hb, lane, [&](uint32_t cnt) {
+                uint32_t f = 0;
+                if constexpr (U2 > 1) {
+                    for (; f + U2 <= cnt; f += U2) {
+                        uint32_t idx[U2], row[U2];
+#pragma unroll
+                        for (int u = 0; u < U2; u++) {
+                            idx[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)hb[f + u]);
+                            row[u] = (idx[u] * Ku) & mask;
+                        }
+                        if (independent(row, idx)) {
+                            float gv[U2][NV][VEC], wo[U2][NV][VEC];
+#pragma unroll
+                            for (int u = 0; u < U2; u++)
+#pragma unroll
+                                for (int j = 0; j < NV; j++) {
+                                    const size_t slot = (size_t)((row[u] + loff[j]) & mask);
+                                    vload<VEC>(g2 + slot, gv[u][j]);
+                                    vload<VEC>(w + slot, wo[u][j]);
+                                }
+#pragma unroll
+                            for (int u = 0; u < U2; u++)
+#pragma unroll
+                                for (int j = 0; j < NV; j++) {
+                                    if (cls[j] < Ku) {
+#pragma unroll
+                                        for (int e = 0; e < VEC; e++) {
+                                            const float d = (gv[u][j][e] > 0.0f) ? upd[j][e] * rsq(gv[u][j][e]) : 0.0f;
+                                            wo[u][j][e] = finish_w(wo[u][j][e], d);
+                                        }
+                                        vstore<VEC>(w + (size_t)((row[u] + cls[j]) & mask), wo[u][j]);
+                                    }
+                                }
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < U2; u++) update_one(idx[u]);
+                        }
+                    }
+                }
+                for (; f < cnt; f++) update_one((uint32_t)__builtin_amdgcn_readfirstlane((int)hb[f]));
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             });
@@ -303,7 +403,9 @@ extern "C" int opal_train_batch(opal_ctx *ctx, const uint8_t *d_reads, uint64_t 
     int grid = sequential ? 1 : (int)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)ctx->num_cus * per_cu));
     float *w = ctx->d_w, *g2 = ctx->d_g2;
     int K = ctx->K;
-    TrainArgs ta{eta, l1, l2, ctx->min_label, ctx->max_label, sequential != 0};
+    int phases = 3;
+    if (const char *e = getenv("OPAL_TRAIN_PHASES")) phases = atoi(e);   // profiling experiments only
+    TrainArgs ta{eta, l1, l2, ctx->min_label, ctx->max_label, sequential != 0, phases};
     void *args[] = {&B, &G, &w, &g2, (void *)&mask, &K, (void *)&const_idx, &d_labels, &ta, &d_out_pred};
     OPAL_HIP_CHECK(ctx, hipLaunchKernel(v.fn, dim3(grid), dim3(BLOCK), args, 0, ctx->stream));
     // keep the wrap padding coherent so that opal_predict can be called between batches
