@@ -19,7 +19,7 @@ import numpy as np
 
 from . import drawfrag, fasta2skm, ldpc
 from . import model as model_io
-from .engine import Engine, PackedReads, Rng, parse_patterns
+from .engine import Engine, GenomeSet, PackedReads, Rng, parse_patterns
 from .fasta_functions import fasta_reader
 from .shard import gather_in_rank_order, shard_range
 
@@ -204,38 +204,46 @@ def train(ref_dir, model_dir, args, engine=None):
         records = list(fasta_reader(f))
     with open(taxids, "r") as f:
         taxid_lines = [l.rstrip("\n") for l in f]
+    # genomes are packed once and stay in HBM; a training batch is only (offset, length, label) per fragment:
+    # the fragments drawfrag would write to train.batch-i.fasta are views into the resident genomes
+    genomes = GenomeSet(eng, PackedReads.from_sequences([s.encode("latin-1") for _, s in records]))
+    genome_len = [len(s) for _, s in records]
+    genome_taxid = [taxid_lines[g] if g < len(taxid_lines) else "" for g in range(len(records))]
 
     seed = 420
     rng = Rng()
     for i in range(num_batches):
         seed = seed + 1                                      # 421, 422, ... (reference opal.py:329)
         print("Drawing fragments for batch {}".format(i))
-        frags, labels = drawfrag.sample_fragments(records, taxid_lines, frag_length, coverage, seed, rng=rng)
-        batch_prefix = os.path.join(model_dir, "train.batch-{}".format(i))
-        taxid_batch = batch_prefix + ".taxid"
-        with open(taxid_batch, "w") as f:                     # same transient file the reference writes and deletes
-            f.write("".join("%s\n" % t for _, t in labels))
+        rng.seed(seed)                                       # drawfrag.main(... "-s", seed) -> random.seed (drawfrag.py:23-24)
+        fpos, fgen = rng.sample_positions(genome_len, frag_length, coverage)
+        n_frag = len(fpos)
+        # the dico assigns ids in first-seen order of the batch's taxid column (fasta2skm.py:30-40): fragments come
+        # genome by genome, so that is the order of the genomes that produced at least one fragment
+        first_seen = [genome_taxid[g] for g in sorted(set(fgen.tolist()))]
+        taxid_batch = os.path.join(model_dir, "train.batch-{}.taxid".format(i))
+        with open(taxid_batch, "w") as f:                     # the transient file the reference writes and deletes
+            f.write("".join("%s\n" % t for t in first_seen))
         with open(taxid_batch, "r") as f:
             label2vwid = fasta2skm.update_dictionary(f, dico)
-        vwid = np.array([label2vwid[t] for _, t in labels], dtype=np.int32)
+        os.remove(taxid_batch)
+        genome_vwid = np.array([label2vwid.get(t, 0) for t in genome_taxid], dtype=np.int32)
+        vwid = genome_vwid[fgen.astype(np.int64)]
         if vwid.size and vwid.max() > num_labels:
             raise ValueError("class id %d exceeds --oaa %d" % (vwid.max(), num_labels))
         print("Getting training set ...")
-        pr = PackedReads.from_sequences([s.encode("latin-1") for s in frags])
         print("Shuffling training set ...")
-        perm = rng.shuffle_perm(len(frags)).astype(np.int64)   # random.shuffle on the same stream (reference opal.py:363)
-        pr = PackedReads(pr.data, np.ascontiguousarray(pr.off[perm]), np.ascontiguousarray(pr.len[perm]))
+        perm = rng.shuffle_perm(n_frag).astype(np.int64)      # random.shuffle on the same stream (reference opal.py:363)
         vwid = np.ascontiguousarray(vwid[perm])
+        batch = genomes.fragments(fpos[perm], fgen[perm], frag_length)
         print("Training on the GPU ...")
         sys.stdout.flush()
-        batch = eng.upload(pr)
         for p in range(max(1, num_passes)):
             pred = eng.train_batch(batch, vwid, reverse, eta=0.5, l1=lambda1, l2=lambda2, want_pred=True)
-            err = float((pred.cpu().numpy() != vwid).mean()) if len(frags) else 0.0
-            msg = "batch %d pass %d: %d examples, progressive error %.4f" % (i, p, len(frags), err)
+            err = float((pred.cpu().numpy() != vwid).mean()) if n_frag else 0.0
+            msg = "batch %d pass %d: %d examples, progressive error %.4f" % (i, p, n_frag, err)
             print(msg)
             log.write(msg + "\n")
-        os.remove(taxid_batch)
     w = eng.get_weights()
     nnz = model_io.save_model(final_model_file, w, num_labels, bits)
     log.write("saved %s (%d non-zero weights)\n" % (final_model_file, nnz))
