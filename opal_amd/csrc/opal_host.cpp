@@ -1,7 +1,6 @@
 // Host-side half of libopal_hip.so: error plumbing, read packing, and the CPython-exact fragment sampler.
 // Nothing here touches the GPU.
 #include <cstring>
-#include <mutex>
 #include <new>
 #include <vector>
 
@@ -9,7 +8,6 @@
 
 namespace opal {
 static thread_local std::string g_err;
-void set_global_error(const std::string &s) { g_err = s; }
 int fail(opal_ctx *ctx, int code, const std::string &msg)
 {
     if (ctx) ctx->err = msg;

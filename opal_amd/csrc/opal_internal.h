@@ -9,7 +9,6 @@
 struct opal_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    bool own_stream = false;
     int num_cus = 256;
     // patterns (util/fasta2skm.py:120-134)
     int k = 0, P = 0, t = 0;
@@ -35,7 +34,6 @@ struct opal_ctx {
 };
 
 namespace opal {
-void set_global_error(const std::string &s);
 int fail(opal_ctx *ctx, int code, const std::string &msg);
 }  // namespace opal
 

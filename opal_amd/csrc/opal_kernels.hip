@@ -343,7 +343,6 @@ extern "C" int opal_ctx_destroy(opal_ctx *ctx)
     if (ctx->ing_seq) (void)hipFree(ctx->ing_seq);
     if (ctx->ing_rec) (void)hipFree(ctx->ing_rec);
     if (ctx->d_block_sums) (void)hipFree(ctx->d_block_sums);
-    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return OPAL_OK;
 }

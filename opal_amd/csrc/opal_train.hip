@@ -439,21 +439,23 @@ extern "C" int opal_load_weights_sparse(opal_ctx *ctx, const uint32_t *idx, cons
     ctx->n_slots = n_slots; ctx->K = K; ctx->bits = bits; ctx->g2_valid = false;
     OPAL_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_w, 0, need * sizeof(float), ctx->stream));
     if (nnz) {
-        uint32_t *d_idx = nullptr;
-        float *d_val = nullptr;
-        OPAL_HIP_CHECK(ctx, hipMalloc((void **)&d_idx, nnz * sizeof(uint32_t)));
-        hipError_t e = hipMalloc((void **)&d_val, nnz * sizeof(float));
-        if (e != hipSuccess) { (void)hipFree(d_idx); return opal::fail(ctx, OPAL_ENOMEM, "opal_load_weights_sparse: hipMalloc failed"); }
-        e = hipMemcpyAsync(d_idx, idx, nnz * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_val, val, nnz * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+        // staging buffers are released on every path
+        struct Staging {
+            uint32_t *idx = nullptr;
+            float *val = nullptr;
+            ~Staging() { if (idx) (void)hipFree(idx); if (val) (void)hipFree(val); }
+        } stg;
+        hipError_t e = hipMalloc((void **)&stg.idx, nnz * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&stg.val, nnz * sizeof(float));
+        if (e != hipSuccess) return opal::fail(ctx, OPAL_ENOMEM, std::string("opal_load_weights_sparse: hipMalloc failed: ") + hipGetErrorString(e));
+        e = hipMemcpyAsync(stg.idx, idx, nnz * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(stg.val, val, nnz * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) {
             const int grid = (int)std::min<uint64_t>((nnz + 255) / 256, 65536);
-            hipLaunchKernelGGL(scatter_weights_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->d_w, d_idx, d_val, nnz, n_slots);
+            hipLaunchKernelGGL(scatter_weights_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->d_w, stg.idx, stg.val, nnz, n_slots);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        (void)hipFree(d_idx);
-        (void)hipFree(d_val);
         if (e != hipSuccess) return opal::fail(ctx, OPAL_EHIP, std::string("opal_load_weights_sparse: ") + hipGetErrorString(e));
     }
     rc = refresh_mirror(ctx);
