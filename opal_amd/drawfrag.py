@@ -56,17 +56,24 @@ def main_not_commandline(args):
         g2t.write("".join("%s\t%s\n" % nl for nl in labels))
 
 
+# same option letters/names as reference util/drawfrag.py:59-66
+_OPTIONS = (
+    ("-i", "--input", dict(help="fasta file to sample from")),
+    ("-l", "--size", dict(type=int, help="fragment length")),
+    ("-t", "--taxids", dict(help="one taxid per fasta record, one per line")),
+    ("-c", "--coverage", dict(type=float, help="target coverage of every record")),
+    ("-g", "--gi2taxid", dict(help="output: '<first word of the record name>\\t<taxid>' per fragment")),
+    ("-s", "--seed", dict(type=int, help="seed of the CPython random stream; unset or 0 leaves it unseeded")),
+    ("-o", "--output", dict(help="output: fragments as fasta records named 1, 2, ...")),
+)
+
+
 def main(argv):
     parser = argparse.ArgumentParser(formatter_class=argparse.RawTextHelpFormatter, description=__doc__)
-    parser.add_argument('--version', action='version', version='%(prog)s {version}'.format(version=__version__))
-    parser.add_argument('-i', '--input', help='file containing input sequences (fasta or fastq) [required]')
-    parser.add_argument('-l', '--size', help='size of drawn items [required]', type=int)
-    parser.add_argument('-t', '--taxids', help='one-column file containing the taxid of each input sequence [required]')
-    parser.add_argument('-c', '--coverage', help='mean coverage value for drawing fragments [required]', type=float)
-    parser.add_argument('-g', '--gi2taxid', help='output gi2taxids file: genome ids and taxids of the drawn fragments [required]')
-    parser.add_argument('-s', '--seed', help='random seed (reproducibility); unset/0 -> unseeded', type=int)
-    parser.add_argument('-o', '--output', help='output sequence file [required]')
-    parser.add_argument('--atgc', help='draw fragments made of ATCG only', action='store_true')
+    parser.add_argument('--version', action='version', version='%(prog)s ' + __version__)
+    for short, long_, kw in _OPTIONS:
+        parser.add_argument(short, long_, **kw)
+    parser.add_argument('--atgc', action='store_true', help='keep only fragments made of A/C/G/T (either case)')
     args = parser.parse_args(argv)
     print(args)
     main_not_commandline(args)

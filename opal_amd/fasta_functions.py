@@ -52,11 +52,14 @@ def reverse_complement(dna):
 
 
 def get_all_substrings(input_string, k):
-    return [input_string[i:i + k] for i in range(len(input_string) - k + 1)]
+    """Every window of length k, left to right; empty when the string is shorter than k (util/fasta_functions.py:53-54)."""
+    n_windows = len(input_string) - k + 1
+    return [input_string[start:start + k] for start in range(max(n_windows, 0))]
 
 
-_pat = re.compile("^[ACGTacgt]*$")
+_ONLY_ACGT = re.compile(r"[ACGTacgt]*$")   # like the reference, `$` also accepts one trailing newline
 
 
 def check_acgt(s):
-    return _pat.match(s)
+    """Truthy when s holds nothing but A/C/G/T in either case (util/fasta_functions.py:57-61)."""
+    return _ONLY_ACGT.match(s)

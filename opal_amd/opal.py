@@ -28,56 +28,53 @@ __version__ = "1.0.0"
 
 # ------------------------------------------------------------------ small file helpers (reference opal.py:52-109)
 def unique_lines(file):
-    '''number of distinct raw lines (reference opal.py:52-58: compares lines including their newline)'''
-    seen = set()
-    with open(file) as f:
-        for line in f:
-            seen.add(line)
-    return len(seen)
+    """How many distinct raw lines the file has.  Lines are compared with their newline, as reference opal.py:52-58
+    does, so a last line without '\n' counts separately from the same text followed by '\n'."""
+    with open(file) as fh:
+        return len(set(fh))
 
 
 def safe_makedirs(directory):
-    if not os.path.exists(directory):
-        os.makedirs(directory)
+    os.makedirs(directory, exist_ok=True)
     return 0
 
 
 def extract_column_two(infile, outfile):
-    """cut -f2 infile > outfile (reference opal.py:65-74)"""
-    with open(infile, 'r') as inf, open(outfile, 'w') as outf:
-        for line in inf:
-            parts = line.split()
-            print(parts[1] if len(parts) > 1 else '', file=outf)
+    """Second whitespace-separated column of every line ('' when a line has fewer than two), one per output line
+    (reference opal.py:65-74)."""
+    with open(infile) as src, open(outfile, "w") as dst:
+        for row in src:
+            cols = row.split()
+            dst.write((cols[1] if len(cols) >= 2 else "") + "\n")
 
 
 def vw_class_to_taxid(inputfile, dicofile, outputfile):
-    '''class ids (one per line) -> taxids via the dico (reference opal.py:76-88); KeyError on an unknown class'''
-    dico = {}
-    with open(dicofile, "r") as fin:
-        for line in fin:
-            txid, vwid = line.strip().split()[:2]
-            dico[vwid] = txid
-    with open(inputfile, "r") as fin, open(outputfile, "w") as predout:
-        for line in fin:
-            predout.write("%s\n" % (dico[str(int(float(line.strip())))]))
+    """Class ids (one per line, '3' or '3.000000') -> taxids through vw-dico.txt (reference opal.py:76-88).
+    An id that the dico does not hold raises KeyError, as in the reference."""
+    with open(dicofile) as fh:
+        by_class = {cols[1]: cols[0] for cols in (ln.strip().split()[:2] for ln in fh)}
+    with open(inputfile) as src, open(outputfile, "w") as dst:
+        dst.writelines(by_class[str(int(float(ln.strip())))] + "\n" for ln in src)
 
 
 def get_fasta_and_taxid(directory):
-    try:
-        fasta = glob.glob(directory + "/*.fasta")[0]
-    except IndexError:
+    """[first *.fasta of the directory, its same-named .taxid]; RuntimeError when either is missing
+    (reference opal.py:90-100)."""
+    found = glob.glob(directory + "/*.fasta")
+    if not found:
         raise RuntimeError("Could not find fasta file in:" + directory)
-    taxids = os.path.splitext(fasta)[0] + ".taxid"
+    taxids = os.path.splitext(found[0])[0] + ".taxid"
     if not os.path.isfile(taxids):
         raise RuntimeError("Could not find matching taxid: " + taxids)
-    return [fasta, taxids]
+    return [found[0], taxids]
 
 
 def get_final_model(directory):
-    try:
-        return glob.glob(directory + "/*_final.model")[0]
-    except IndexError:
+    """First file matching *_final.model (reference opal.py:102-109)."""
+    found = glob.glob(directory + "/*_final.model")
+    if not found:
         raise RuntimeError("Could not find final model file in: " + directory)
+    return found[0]
 
 
 def evaluate_predictions(reffile, predfile):
@@ -309,60 +306,52 @@ def predict(model_dir, test_dir, predict_dir, args, engine=None, chunk=2_000_000
     return prefix + '.preds.taxid'
 
 
-class ArgClass:
-    '''holder so that flag definitions are shared between sub-parsers'''
-    def __init__(self, *args, **kwargs):
-        self.args = args
-        self.kwargs = kwargs
+# flag table: (short, long, argparse kwargs).  Names, types and defaults are those of reference opal.py:519-545.
+_FLAGS = {
+    "frag_length": ("-l", "--frag-length", dict(type=int, default=64, help="fragment length drawn from each fasta record")),
+    "kmer": ("-k", "--kmer", dict(type=int, default=64, help="k-mer (window) length")),
+    "coverage": ("-c", "--coverage", dict(type=float, default=15.0, help="how many times over each genome is covered by fragments")),
+    "reverse": ("-r", "--reverse-complement", dict(action="store_true", help="also use the reverse complement of every fragment")),
+    "hierarchical": (None, "--hierarchical-weight", dict(type=int, default=-1, help="accepted and validated like the reference; the pattern generator ignores it there too")),
+    "row_weight": (None, "--row-weight", dict(type=int, default=16, help="positions kept per spaced k-mer; must divide the k-mer length")),
+    "num_hash": (None, "--num-hash", dict(type=int, default=8, help="number of LDPC patterns (hash functions) besides the contiguous prefix")),
+    "num_batches": (None, "--num-batches", dict(type=int, default=1, help="number of freshly sampled training batches")),
+    "num_passes": (None, "--num-passes", dict(type=int, default=1, help="learner passes over each batch")),
+    "bits": (None, "--bits", dict(type=int, default=31, help="log2 of the number of weight slots")),
+    "lambda1": (None, "--lambda1", dict(type=float, default=0., help="l1 regularisation")),
+    "lambda2": (None, "--lambda2", dict(type=float, default=0., help="l2 regularisation")),
+}
+_TRAIN_FLAGS = ("frag_length", "coverage", "kmer", "reverse", "num_batches", "num_passes", "num_hash", "row_weight",
+                "hierarchical", "bits", "lambda1", "lambda2")
+# sub-command -> (help, positional (name, help) pairs, flags)
+_COMMANDS = {
+    "frag": ("cut a fasta file into random fragments", (("test_dir", "directory with one .fasta and its .taxid"),
+                                                       ("frag_dir", "output directory")), ("frag_length", "coverage")),
+    "train": ("learn a model from reference genomes", (("train_dir", "directory with one .fasta and its .taxid"),
+                                                      ("model_dir", "output directory")), _TRAIN_FLAGS),
+    "predict": ("classify fragments with a trained model", (("model_dir", "directory written by train"),
+                                                           ("test_dir", "directory with the fragments' .fasta"),
+                                                           ("predict_dir", "output directory")), ("reverse", "kmer")),
+    "eval": ("score predicted labels against a gold standard", (("reference_file", "one true label per line"),
+                                                               ("predicted_labels", "one predicted label per line")), ()),
+    "simulate": ("frag, train, predict and eval in one go", (("test_dir", "test genomes"), ("train_dir", "training genomes"),
+                                                            ("out_dir", "output directory (1frag, 2model, 3predict)")), _TRAIN_FLAGS),
+}
 
 
 def build_parser():
     parser = argparse.ArgumentParser(formatter_class=argparse.RawTextHelpFormatter, description=__doc__)
-    parser.add_argument('--version', action='version', version='%(prog)s {version}'.format(version=__version__))
-    # same flags and defaults as reference opal.py:519-545
-    frag_length_arg = ArgClass("-l", "--frag-length", help="length of fragments to be drawn from fasta", type=int, default=64)
-    kmer_arg = ArgClass("-k", "--kmer", help="length of k-mers used", type=int, default=64)
-    coverage_arg = ArgClass("-c", "--coverage", help="number/fraction of times each location in a fragment should be covered by a k-mer", type=float, default=15.0)
-    reverse_complement_arg = ArgClass("-r", "--reverse-complement", help="Also trains and evaluates on reverse complements of ACGT DNA strings", action="store_true")
-    hierarchical_arg = ArgClass("--hierarchical-weight", help="intermediate organization of positions chosen in the k-mer in row_weight; should be a multiple of row_weight and a divisor of k-mer length if set", type=int, default=-1)
-    row_weight_arg = ArgClass("--row-weight", help="the number of positions that will be randomly chosen in the contiguous k-mer; k-mer length should be a multiple of row_weight", type=int, default=16)
-    num_hash_arg = ArgClass("--num-hash", help="number of k-mer hashing functions to get features", type=int, default=8)
-    num_batches_arg = ArgClass("--num-batches", help="Number of times to generate a random batch of training data", type=int, default=1)
-    num_passes_arg = ArgClass("--num-passes", help="Number of passes in each training batch", type=int, default=1)
-    bits_arg = ArgClass("--bits", help="Number of bits used in the model's hash table", type=int, default=31)
-    lambda1_arg = ArgClass("--lambda1", help="l1 training parameter", type=float, default=0.)
-    lambda2_arg = ArgClass("--lambda2", help="l2 training parameter", type=float, default=0.)
-    train_args = [frag_length_arg, coverage_arg, kmer_arg, reverse_complement_arg, num_batches_arg, num_passes_arg,
-                  num_hash_arg, row_weight_arg, hierarchical_arg, bits_arg, lambda1_arg, lambda2_arg]
-
+    parser.add_argument('--version', action='version', version='%(prog)s ' + __version__)
     sub = parser.add_subparsers(help="sub-commands", dest="mode")
-    fmt = argparse.ArgumentDefaultsHelpFormatter
-    p = sub.add_parser("frag", help="Fragment a fasta file into substrings for training/testing", formatter_class=fmt)
-    p.add_argument("test_dir", help="Input directory for test data")
-    p.add_argument("frag_dir", help="Output directory for fasta fragments")
-    for a in (frag_length_arg, coverage_arg):
-        p.add_argument(*a.args, **a.kwargs)
-    p = sub.add_parser("train", help="Train a model using Opal hashes", formatter_class=fmt)
-    p.add_argument("train_dir", help="Input directory for train data")
-    p.add_argument("model_dir", help="Output directory for the model")
-    for a in train_args:
-        p.add_argument(*a.args, **a.kwargs)
-    p = sub.add_parser("predict", help="Predict metagenomic classifications given a Opal model", formatter_class=fmt)
-    p.add_argument("model_dir", help="Input directory for the model")
-    p.add_argument("test_dir", help="Input directory for already fragmented test data")
-    p.add_argument("predict_dir", help="Output directory for predictions")
-    for a in (reverse_complement_arg, kmer_arg):
-        p.add_argument(*a.args, **a.kwargs)
-    p = sub.add_parser('eval', help="Evaluate quality of predictions given a reference", formatter_class=fmt)
-    p.add_argument("reference_file", help="Gold standard labels")
-    p.add_argument("predicted_labels", help="Predicted labels")
-    p = sub.add_parser('simulate', help="Run a full pipeline of frag, train, predict, and eval", formatter_class=fmt)
-    p.add_argument("test_dir", help="Input directory for test data")
-    p.add_argument("train_dir", help="Input directory for train data")
-    p.add_argument("out_dir", help="Output directory for all steps")
-    p.add_argument("--do-not-fragment", help="If set, will use test_dir fasta files as is without fragmenting", action="store_true")
-    for a in train_args:
-        p.add_argument(*a.args, **a.kwargs)
+    for name, (text, positionals, flags) in _COMMANDS.items():
+        p = sub.add_parser(name, help=text, formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+        for pos_name, pos_help in positionals:
+            p.add_argument(pos_name, help=pos_help)
+        if name == "simulate":
+            p.add_argument("--do-not-fragment", action="store_true", help="use the test fasta as it is")
+        for key in flags:
+            short, long_, kw = _FLAGS[key]
+            p.add_argument(*([short, long_] if short else [long_]), **kw)
     return parser
 
 
