@@ -312,3 +312,63 @@ def test_gpu_fasta_ingest_matches_reference_reader(amd, eng, oracle, golden_dir)
     c1, _ = eng.predict(eng.ingest_fasta(big), True)
     c2, _ = eng.predict(eng.upload(amd.PackedReads.from_sequences(seqs)), True)
     assert np.array_equal(c1.cpu().numpy(), c2.cpu().numpy())
+
+
+def test_full_size_configs_properties(amd, oracle, golden_dir):
+    """BASELINE.json configs 2 and 3 at their real sizes (1M x 200bp, K=356 / K=1564 shard, 2^31-slot table):
+    size-independent properties + the oracle on a bounded sample."""
+    import torch
+    from opal_amd.engine import DeviceBatch
+    eng = amd.Engine(0)
+    dev = eng.device
+    rng = np.random.default_rng(31)
+    n, L, bits = 1_000_000, 200, 31
+    pos = _patterns(amd, golden_dir, "patterns_k64_t16_m1_s7.txt", 64)
+    eng.set_patterns(pos, 64)
+    codes = rng.integers(0, 4, size=(n, L), dtype=np.uint8)
+    batch = eng.upload(amd.PackedReads.from_codes(codes))
+    # emit at full size: every index equals the multi-threaded oracle's (and so does the checksum)
+    blob = ACGT[codes].reshape(-1)
+    soff = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    idx, off = eng.features(batch, True, bits)
+    oidx, ooff = oracle.features_batch((blob, soff), 64, pos, True, bits, nthreads=0)
+    assert np.array_equal(off.cpu().numpy().view(np.uint64), ooff)
+    assert np.array_equal(_u32(idx), oidx)
+    del idx, oidx
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    w = torch.empty(1 << bits, dtype=torch.float32, device=dev)
+    w.normal_(0.0, 0.05, generator=g)
+    wh = w.cpu().numpy()
+
+    def view(lo, hi):
+        return DeviceBatch(batch.data, batch.off[lo:hi], batch.len[lo:hi], hi - lo, batch.nbytes)
+
+    for K, m in ((356, 1_000_000), (1564, 250_000)):
+        eng.load_weights(w, K, bits)
+        eng.set_vw_options(clip=False)
+        cls, sc = eng.predict(view(0, m), True, want_scores=True)
+        cls, sc = cls.clone(), sc.clone()
+        # sharding invariance: three uneven shards give the same per-fragment classes and scores
+        cuts = [0, m // 7, m // 7 + m // 3, m]
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            c, s = eng.predict(view(lo, hi), True, want_scores=True)
+            assert torch.equal(c, cls[lo:hi]) and torch.equal(s, sc[lo:hi])
+        # the oracle on a bounded sample (first 1500 fragments), bit for bit
+        ms = 1500
+        ocls, osc, _ = oracle.predict((blob[:ms * L + 1], soff[:ms + 1]), 64, pos, True, wh, K, bits, clip=False, nthreads=0)
+        assert np.array_equal(sc[:ms].cpu().numpy(), osc) and np.array_equal(cls[:ms].cpu().numpy(), ocls)
+        # exact power-of-two scaling of the whole table
+        w.mul_(2.0)
+        eng.load_weights(w, K, bits)
+        c2, s2 = eng.predict(view(0, m), True, want_scores=True)
+        assert torch.equal(s2, sc * 2.0) and torch.equal(c2, cls)
+        w.mul_(0.5)
+        # VW defaults (clip to [-1,1]): classes still agree with the oracle on the sample
+        eng.load_weights(w, K, bits)
+        eng.set_vw_options()
+        c3, _ = eng.predict(view(0, ms), True)
+        o3, _, _ = oracle.predict((blob[:ms * L + 1], soff[:ms + 1]), 64, pos, True, wh, K, bits, want_scores=False, nthreads=0)
+        assert np.array_equal(c3.cpu().numpy(), o3)
+        del c2, s2, sc, cls
+    eng.close()
