@@ -372,3 +372,77 @@ def test_full_size_configs_properties(amd, oracle, golden_dir):
         assert np.array_equal(c3.cpu().numpy(), o3)
         del c2, s2, sc, cls
     eng.close()
+
+
+def test_randomised_geometries_against_oracle(amd, eng, oracle):
+    """Seeded fuzz over pattern geometry (k, t, P), fragment lengths (around every tile/buffer boundary), packed/raw
+    storage, views at every base phase, K, bits and VW switches: emit and predict must equal the oracle every time."""
+    rng = np.random.default_rng(20240611)
+    alphabets = [ACGT, np.frombuffer(b"ACGTacgtNn", dtype=np.uint8), np.frombuffer(b"0123456789", dtype=np.uint8)]
+    for trial in range(70):
+        t = int(rng.choice([1, 2, 3, 4, 5, 8, 12, 16, 16, 16, 32, 64]))
+        mult = int(rng.integers(1, max(2, min(8, 256 // t) + 1)))
+        k = t * mult
+        P = int(rng.choice([1, 2, 2, 3, 5, 9, 10, 11, 17, 64]))
+        pos = np.stack([np.sort(rng.choice(k, size=t, replace=False)) for _ in range(P)]).astype(np.int32)
+        eng.set_patterns(pos, k)
+        lens = [int(x) for x in rng.choice([0, 1, k - 1, k, k + 1, k + 63, k + 64, k + 65, 200, 255, 256, 257, 511, 512, 513,
+                                            700, 1536 // max(P, 1) + k, 2000], size=12)]
+        seqs = []
+        for L in lens:
+            a = alphabets[0] if rng.random() < 0.7 else alphabets[int(rng.integers(1, 3))]
+            seqs.append(bytes(rng.choice(a, size=max(L, 0))))
+        reverse = bool(rng.integers(0, 2))
+        hash_all = bool(rng.integers(0, 2))
+        bits = int(rng.choice([8, 12, 16, 20, 31, 32]))
+        eng.set_vw_options(hash_all=hash_all)
+        batch = eng.upload(amd.PackedReads.from_sequences(seqs))
+        idx, off = eng.features(batch, reverse, bits)
+        oidx, ooff = oracle.features_batch(seqs, k, pos, reverse, bits, hash_all=hash_all)
+        assert np.array_equal(off.cpu().numpy().view(np.uint64), ooff), trial
+        assert np.array_equal(_u32(idx), oidx), (trial, k, t, P)
+    eng.set_vw_options()
+
+
+def test_randomised_predict_switches_against_oracle(amd, eng, oracle):
+    rng = np.random.default_rng(77001)
+    for trial in range(40):
+        t = int(rng.choice([4, 8, 16, 16, 32]))
+        k = t * int(rng.integers(1, 5))
+        P = int(rng.choice([1, 2, 3, 5, 9, 12]))
+        pos = np.stack([np.sort(rng.choice(k, size=t, replace=False)) for _ in range(P)]).astype(np.int32)
+        eng.set_patterns(pos, k)
+        seqs = [bytes(rng.choice(ACGT if rng.random() < 0.8 else np.frombuffer(b"ACGTNacgt", dtype=np.uint8),
+                                 size=int(rng.choice([0, k - 1, k, k + 7, 150, 200, 256, 257, 600, 1700])))) for _ in range(10)]
+        reverse, hash_all = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        addc, clip = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        bits = int(rng.choice([8, 12, 16, 20]))
+        K = int(rng.choice([1, 2, 3, 4, 10, 63, 64, 65, 200, 356, 513, 700, 2052]))
+        w = (rng.standard_normal(1 << bits) * 0.1).astype(np.float32)
+        eng.load_weights(w, K, bits)
+        eng.set_vw_options(hash_all=hash_all, add_constant=addc, clip=clip, min_label=-0.5, max_label=0.75)
+        # half of the trials score views into one packed "genome" holding all sequences back to back
+        if trial % 2:
+            genome = b"".join(s for s in seqs if all(c in b"ACGT" for c in s))
+            starts, frs, o = [], [], 0
+            for s in seqs:
+                if all(c in b"ACGT" for c in s):
+                    starts.append(o)
+                    frs.append(s)
+                    o += len(s)
+            gs = amd.GenomeSet(eng, amd.PackedReads.from_sequences([genome]))
+            # equal-length requirement of GenomeSet.fragments: one call per fragment length
+            for s0, fr in zip(starts, frs):
+                b1 = gs.fragments(np.array([s0]), np.array([0]), len(fr))
+                c1, s1 = eng.predict(b1, reverse, want_scores=True)
+                oc, osc, _ = oracle.predict([fr], k, pos, reverse, w, K, bits, add_constant=addc, clip=clip,
+                                            min_label=-0.5, max_label=0.75, hash_all=hash_all)
+                assert np.array_equal(s1.cpu().numpy(), osc) and np.array_equal(c1.cpu().numpy(), oc), (trial, s0, len(fr))
+        else:
+            batch = eng.upload(amd.PackedReads.from_sequences(seqs))
+            cls, sc = eng.predict(batch, reverse, want_scores=True)
+            ocls, osc, _ = oracle.predict(seqs, k, pos, reverse, w, K, bits, add_constant=addc, clip=clip,
+                                          min_label=-0.5, max_label=0.75, hash_all=hash_all)
+            assert np.array_equal(sc.cpu().numpy(), osc), (trial, k, t, P, K, bits)
+            assert np.array_equal(cls.cpu().numpy(), ocls), (trial, k, t, P, K, bits)
+    eng.set_vw_options()
