@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--workload", default="cfg2_356sp_1M", choices=sorted(WORKLOADS))
     ap.add_argument("--nfrag", type=int, default=0, help="override fragments per GPU")
     ap.add_argument("--bits", type=int, default=0, help="override table bits")
+    ap.add_argument("--classes", type=int, default=0, help="override the class count K (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=300_000)
     args = ap.parse_args()
@@ -116,6 +117,8 @@ def main():
         wl["n"] = args.nfrag
     if args.bits:
         wl["bits"] = args.bits
+    if args.classes:
+        wl["K"] = args.classes
     K, n, bits, mode = wl["K"], wl["n"], wl["bits"], wl["mode"]
     L, k = 200, 64
     with open(os.path.join(ROOT, "tests", "golden", wl["pattern"])) as f:
@@ -196,7 +199,7 @@ def main():
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             with open(tp) as f:
-                traffic = json.load(f).get(args.workload if not (args.nfrag or args.bits) else "", {}).get("hbm_bytes_per_launch")
+                traffic = json.load(f).get(args.workload if not (args.nfrag or args.bits or args.classes) else "", {}).get("hbm_bytes_per_launch")
         res = {
             "metric": "fragments/sec", "value": frag_per_s, "unit": "fragments/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",

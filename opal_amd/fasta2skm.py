@@ -8,15 +8,19 @@ The fast path never builds text: opal.predict() feeds packed fragments straight 
 generator exists for parity tests and for `--dump-vw-text`; the characters of every feature are gathered on the
 GPU (opal_feature_names), only the string formatting happens here.
 """
+import argparse
 import itertools
 import os
+import sys
 
 import numpy as np
 
 from .engine import Engine, PackedReads, parse_patterns
 from .fasta_functions import fasta_reader
 
-__all__ = ["update_dictionary", "create_pattern_getters", "main_generator", "vw_text_lines", "load_labels"]
+__all__ = ["update_dictionary", "create_pattern_getters", "main_generator", "main_not_commandline", "main",
+           "vw_text_lines", "load_labels"]
+__version__ = "0.0.2"
 
 create_pattern_getters = parse_patterns
 
@@ -95,3 +99,33 @@ def main_generator(args, engine=None):
     lab = iter(labels) if labels is not None else None
     for line in vw_text_lines(eng, seqs, bool(args.reverse), lab):
         yield line.decode("latin-1")
+
+
+def main_not_commandline(args):
+    """Writes the lines of main_generator to args.output ('-' = stdout), like util/fasta2skm.py:87-96."""
+    out = sys.stdout if args.output == "-" else open(args.output, "w", encoding="latin-1")
+    try:
+        for line in main_generator(args):
+            out.write(line)
+    finally:
+        if out is not sys.stdout:
+            out.close()
+
+
+def main(argv):
+    """Same options as the reference's stand-alone tool (util/fasta2skm.py:99-117)."""
+    parser = argparse.ArgumentParser(formatter_class=argparse.RawTextHelpFormatter, description=__doc__)
+    parser.add_argument('--version', action='version', version='%(prog)s ' + __version__)
+    for short, long_, kw in (("-i", "--input", dict(help="fasta/fastq file to featurise")),
+                             ("-k", "--kmer", dict(type=int, help="window length")),
+                             ("-t", "--taxid", dict(help="one label per record; without it every line is labelled 1")),
+                             ("-p", "--pattern", dict(help="patterns.txt (LDPC positions); without it the whole k-mer is one feature")),
+                             ("-d", "--dico", dict(help="label <-> class id table, created/extended (needed with --taxid)")),
+                             ("-o", "--output", dict(default="-", help="output file, '-' = stdout"))):
+        parser.add_argument(short, long_, **kw)
+    parser.add_argument('-r', '--reverse', action='store_true', help='append the reverse complement strand\'s features')
+    main_not_commandline(parser.parse_args(argv))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

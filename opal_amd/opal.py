@@ -279,6 +279,11 @@ def predict(model_dir, test_dir, predict_dir, args, engine=None, chunk=2_000_000
     eng = engine or Engine(local)
     eng.set_patterns(pos, kmer)
     hdr = model_io.load_model(model, eng)
+    if getattr(args, "dump_vw_text", None) and rank == 0:
+        ns = argparse.Namespace(input=fasta, taxid=None, kmer=kmer, dico=None, output=args.dump_vw_text, pattern=pattern_file,
+                                reverse=reverse)
+        with open(args.dump_vw_text, "w", encoding="latin-1") as f:
+            f.writelines(fasta2skm.main_generator(ns, engine=eng))
     # the file's bytes go to HBM as they are; records are split and 2-bit packed on the device (opal_ingest_fasta)
     whole = eng.ingest_fasta(fasta)
     n_frag = whole.n
@@ -349,6 +354,9 @@ def build_parser():
             p.add_argument(pos_name, help=pos_help)
         if name == "simulate":
             p.add_argument("--do-not-fragment", action="store_true", help="use the test fasta as it is")
+        if name == "predict":
+            p.add_argument("--dump-vw-text", metavar="FILE", default=None,
+                           help="debug: also write the VW text lines the reference would pipe to vw (byte-identical)")
         for key in flags:
             short, long_, kw = _FLAGS[key]
             p.add_argument(*([short, long_] if short else [long_]), **kw)

@@ -446,3 +446,27 @@ def test_randomised_predict_switches_against_oracle(amd, eng, oracle):
             assert np.array_equal(sc.cpu().numpy(), osc), (trial, k, t, P, K, bits)
             assert np.array_equal(cls.cpu().numpy(), ocls), (trial, k, t, P, K, bits)
     eng.set_vw_options()
+
+
+def test_fasta2skm_tool_and_dump_vw_text_match_reference_lines(amd, eng, golden_dir, tmp_path):
+    """The stand-alone fasta2skm tool (util/fasta2skm.py:99-117 mirror) writes the reference's lines, labels included."""
+    from opal_amd import fasta2skm
+    cases = {c["name"]: c for c in _load(golden_dir, "skm.json")}
+    c = cases["edge_m4_r1"]
+    fa = tmp_path / "in.fasta"
+    fa.write_bytes(c["fasta"].encode("latin-1"))
+    out = tmp_path / "out.vw"
+    fasta2skm.main(["-i", str(fa), "-k", "64", "-p", os.path.join(golden_dir, c["pattern"]), "-o", str(out), "-r"])
+    assert out.read_bytes().decode("latin-1") == "".join(c["lines"])
+    d = _load(golden_dir, "dico.json")[0]
+    fa.write_text(d["fasta"])
+    tx, dico = tmp_path / "in.taxid", tmp_path / "dico.txt"
+    tx.write_text(d["taxid"])
+    fasta2skm.main(["-i", str(fa), "-k", "64", "-p", os.path.join(golden_dir, "patterns_k64_t16_m1_s7.txt"), "-t", str(tx),
+                    "-d", str(dico), "-o", str(out)])
+    assert [l.split(" ", 1)[0] for l in out.read_text().splitlines()] == d["labels"]
+    assert dico.read_text() == d["dico_out"]
+    with pytest.raises(ValueError):
+        fasta2skm.main(["-i", str(fa), "-k", "64", "-t", str(tx)])           # --taxid without --dico (fasta2skm.py:57-58)
+    with pytest.raises(ValueError):
+        fasta2skm.main(["-k", "64"])                                         # no input (fasta2skm.py:52-53)
