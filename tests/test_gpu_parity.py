@@ -470,3 +470,28 @@ def test_fasta2skm_tool_and_dump_vw_text_match_reference_lines(amd, eng, golden_
         fasta2skm.main(["-i", str(fa), "-k", "64", "-t", str(tx)])           # --taxid without --dico (fasta2skm.py:57-58)
     with pytest.raises(ValueError):
         fasta2skm.main(["-k", "64"])                                         # no input (fasta2skm.py:52-53)
+
+
+def test_plain_c_client_of_the_cabi(oracle, golden_dir, tmp_path):
+    """examples/predict_c (C, hipMalloc, no Python/torch in the process) gives the oracle's classes."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "predict_c")
+    assert os.path.exists(exe), "examples/predict_c is built by __graft_entry__.build()"
+    rng = np.random.default_rng(4)
+    K, bits = 356, 18
+    with open(os.path.join(golden_dir, "patterns_k64_t16_m1_s7.txt")) as f:
+        pos = oracle.parse_patterns(f.readlines(), 64)
+    seqs = _rand_seqs(rng, 300, 200)
+    seqs[7] = seqs[7].lower()
+    seqs[9] = seqs[9][:50]
+    w = (rng.standard_normal(1 << bits) * 0.05).astype(np.float32)
+    w.tofile(tmp_path / "w.f32")
+    (tmp_path / "reads.txt").write_bytes(b"".join(s + b"\n" for s in seqs))
+    out = tmp_path / "out.txt"
+    r = subprocess.run([exe, os.path.join(golden_dir, "patterns_k64_t16_m1_s7.txt"), "64", str(tmp_path / "w.f32"), str(K),
+                        str(bits), str(tmp_path / "reads.txt"), str(out), "1"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    got = np.array([int(x) for x in out.read_text().split()], dtype=np.int32)
+    ocls, _, _ = oracle.predict(seqs, 64, pos, True, w, K, bits, want_scores=False)
+    assert np.array_equal(got, ocls)
