@@ -116,3 +116,69 @@ def test_shard_ranges_partition():
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
             assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+def test_model_container_roundtrip_on_cpu(tmp_path):
+    """opal_amd/model.py without a GPU: header fields, sparse and dense payloads, and the error on foreign files."""
+    from opal_amd import model as model_io
+
+    class FakeEngine:                                   # records what load_model hands to the GPU context
+        def load_weights(self, w, K, bits):
+            self.dense = (np.array(w), K, bits)
+
+        def load_weights_sparse(self, idx, val, K, bits):
+            self.sparse = (np.array(idx), np.array(val), K, bits)
+
+        def set_vw_options(self, *a):
+            self.opts = a
+
+    rng = np.random.default_rng(0)
+    w = np.zeros(1 << 14, dtype=np.float32)
+    nz = rng.choice(1 << 14, size=500, replace=False)
+    w[nz] = rng.standard_normal(500).astype(np.float32)
+    p = str(tmp_path / "vw-model_final.model")
+    assert model_io.save_model(p, w, 7, 14, hash_all=True, add_constant=False, clip=True, min_label=-2.0, max_label=3.0) == 500
+    h = model_io.read_header(p)
+    assert (h["bits"], h["K"], h["nnz"], h["dense"]) == (14, 7, 500, False)
+    assert (h["hash_all"], h["add_constant"], h["clip"], h["min_label"], h["max_label"]) == (True, False, True, -2.0, 3.0)
+    e = FakeEngine()
+    model_io.load_model(p, e)
+    idx, val, K, bits = e.sparse
+    back = np.zeros_like(w)
+    back[idx] = val
+    assert np.array_equal(back, w) and (K, bits) == (7, 14) and e.opts == (True, False, True, -2.0, 3.0)
+    wd = rng.standard_normal(1 << 10).astype(np.float32)
+    p2 = str(tmp_path / "dense_final.model")
+    model_io.save_model(p2, wd, 3, 10)
+    e2 = FakeEngine()
+    assert model_io.load_model(p2, e2)["dense"] and np.array_equal(e2.dense[0], wd)
+    bad = tmp_path / "x_final.model"
+    bad.write_bytes(b"\x06\x00\x00\x008.6.1\x00m")      # how a VW binary regressor starts
+    with pytest.raises(RuntimeError):
+        model_io.read_header(str(bad))
+
+
+def test_cli_parser_matches_reference_defaults():
+    """Flags and defaults of reference opal.py:519-545."""
+    from opal_amd import opal
+    p = opal.build_parser()
+    a = p.parse_args(["train", "in", "out"])
+    assert (a.frag_length, a.kmer, a.coverage, a.reverse_complement, a.row_weight, a.num_hash, a.num_batches, a.num_passes,
+            a.bits, a.lambda1, a.lambda2, a.hierarchical_weight) == (64, 64, 15.0, False, 16, 8, 1, 1, 31, 0.0, 0.0, -1)
+    a = p.parse_args(["simulate", "t", "tr", "o", "-r", "-l", "200", "-c", "0.1", "--do-not-fragment"])
+    assert a.do_not_fragment and a.reverse_complement and a.frag_length == 200 and a.coverage == 0.1
+    a = p.parse_args(["predict", "m", "t", "p", "-k", "32"])
+    assert a.kmer == 32 and not a.reverse_complement and not hasattr(a, "bits")
+    a = p.parse_args(["frag", "t", "f"])
+    assert (a.frag_length, a.coverage) == (64, 15.0)
+    with pytest.raises(ValueError):                      # reference opal.py:248-249
+        import argparse
+        ns = argparse.Namespace(frag_length=64, coverage=1.0, kmer=64, row_weight=10, hierarchical_weight=-1, num_hash=1,
+                                num_batches=1, num_passes=1, bits=20, lambda1=0.0, lambda2=0.0, reverse_complement=False)
+        import tempfile
+        d = tempfile.mkdtemp()
+        open(os.path.join(d, "a.fasta"), "w").write(">g\nACGT\n")
+        open(os.path.join(d, "a.taxid"), "w").write("1\n")
+        opal.train(d, os.path.join(d, "m"), ns)
+    with pytest.raises(RuntimeError):                    # reference opal.py:93-96
+        opal.get_fasta_and_taxid(tempfile.mkdtemp())
