@@ -110,6 +110,17 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
                     gsq[j][e] = 4.0f * err[j][e] * err[j][e];
                     ppu[j][e] = 0.0f;
                 }
+            // classes whose clipped prediction already equals the label (err == 0: typically most of the K-1 negatives
+            // of a trained model, saturated at -1) change neither G nor w: their lanes skip sweeps 2 and 3 entirely
+            const bool reg_on = (ta.l1 != 0.0f) || (ta.l2 != 0.0f);
+            bool act[NV];
+#pragma unroll
+            for (int j = 0; j < NV; j++) {
+                bool any = reg_on;
+#pragma unroll
+                for (int e = 0; e < VEC; e++) any = any || (err[j][e] != 0.0f);
+                act[j] = any && (cls[j] < Ku);
+            }
             const float s = ta.eta / sqrtf((float)nfeat);
             // Sweeps 2 and 3 keep U2 rows in flight when the rows of a group cannot touch the same slot (VW's layout
             // lets rows overlap: |row_a - row_b| mod 2^b < K); otherwise, and for the constant row in concurrent
@@ -136,7 +147,7 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
                 const bool shared_row = (idx == const_idx) && !ta.sequential;
 #pragma unroll
                 for (int j = 0; j < NV; j++) {
-                    if (cls[j] < Ku) {
+                    if (act[j]) {
                         float *gp = g2 + (size_t)((row + cls[j]) & mask);
                         float gv[VEC];
                         if (shared_row) {   // every example touches the constant row: returning atomics, no lost adds
@@ -169,12 +180,13 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
 #pragma unroll
                             for (int u = 0; u < U2; u++)
 #pragma unroll
-                                for (int j = 0; j < NV; j++) vload<VEC>(g2 + (size_t)((row[u] + loff[j]) & mask), gv[u][j]);
+                                for (int j = 0; j < NV; j++)
+                                    if (act[j]) vload<VEC>(g2 + (size_t)((row[u] + cls[j]) & mask), gv[u][j]);
 #pragma unroll
                             for (int u = 0; u < U2; u++)
 #pragma unroll
                                 for (int j = 0; j < NV; j++) {
-                                    if (cls[j] < Ku) {
+                                    if (act[j]) {
 #pragma unroll
                                         for (int e = 0; e < VEC; e++) {
                                             gv[u][j][e] += gsq[j][e];
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
                 const bool shared_row = (idx == const_idx) && !ta.sequential;
 #pragma unroll
                 for (int j = 0; j < NV; j++) {
-                    if (cls[j] < Ku) {
+                    if (act[j]) {
                         const size_t slot = (size_t)((row + cls[j]) & mask);
                         float gv[VEC], d[VEC];
                         vload<VEC>(g2 + slot, gv);
@@ -257,15 +269,17 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
                             for (int u = 0; u < U2; u++)
 #pragma unroll
                                 for (int j = 0; j < NV; j++) {
-                                    const size_t slot = (size_t)((row[u] + loff[j]) & mask);
-                                    vload<VEC>(g2 + slot, gv[u][j]);
-                                    vload<VEC>(w + slot, wo[u][j]);
+                                    if (act[j]) {
+                                        const size_t slot = (size_t)((row[u] + cls[j]) & mask);
+                                        vload<VEC>(g2 + slot, gv[u][j]);
+                                        vload<VEC>(w + slot, wo[u][j]);
+                                    }
                                 }
 #pragma unroll
                             for (int u = 0; u < U2; u++)
 #pragma unroll
                                 for (int j = 0; j < NV; j++) {
-                                    if (cls[j] < Ku) {
+                                    if (act[j]) {
 #pragma unroll
                                         for (int e = 0; e < VEC; e++) {
                                             const float d = (gv[u][j][e] > 0.0f) ? upd[j][e] * rsq(gv[u][j][e]) : 0.0f;

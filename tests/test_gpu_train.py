@@ -192,3 +192,27 @@ def test_vw_readable_model_import(amd, tmp_path):
     w = eng.get_weights(to_host=True)
     assert w[5] == 0.25 and w[17] == -1.5 and w[4095] == 2.0 and np.count_nonzero(w) == 3
     eng.close()
+
+
+def test_saturated_classes_skip_updates_but_keep_the_rule(amd, oracle, golden_dir):
+    """A model whose negatives already sit at -1 (err == 0 after the clip): the kernel skips those classes' rows, the
+    oracle's sequential rule adds zeros; both must leave the same table."""
+    rng = np.random.default_rng(12)
+    with open(os.path.join(golden_dir, "patterns_k64_t16_m1_s7.txt")) as f:
+        pos = amd.parse_patterns(f.readlines(), 64)
+    K, bits = 40, 16
+    seqs = [bytes(rng.choice(ACGT, size=200)) for _ in range(20)]
+    labels = rng.integers(1, K + 1, size=len(seqs)).astype(np.int32)
+    w0 = np.full(1 << bits, -0.01, dtype=np.float32)      # 549 features x -0.01 = -5.49 -> every class clips to -1
+    eng = amd.Engine(0)
+    eng.set_patterns(pos, 64)
+    eng.load_weights(w0, K, bits)
+    eng.train_begin(K, bits, resume=True)
+    batch = eng.upload(amd.PackedReads.from_sequences(seqs))
+    w, g2 = w0.copy(), np.zeros(1 << bits, dtype=np.float32)
+    eng.train_batch(batch, labels, True, sequential=True)
+    oracle.train(seqs, labels, 64, pos, True, w, g2, K, bits)
+    gw = eng.get_weights(to_host=True)
+    assert np.allclose(gw, w, rtol=2e-4, atol=1e-6)
+    assert (gw != w0).sum() > 0 and (gw != w0).mean() < 0.5      # only the true classes' slots moved
+    eng.close()
