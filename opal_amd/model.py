@@ -20,9 +20,17 @@ _HDR = struct.Struct("<8sIIIIffQII")
 __all__ = ["save_model", "load_model", "read_header", "import_vw_readable_model"]
 
 
+def _count_nonzero(w, chunk=1 << 27):
+    """Number of non-zero entries, scanned in chunks (on the device for a torch tensor)."""
+    n = w.shape[0]
+    if isinstance(w, np.ndarray):
+        return int(sum(int(np.count_nonzero(w[s:s + chunk])) for s in range(0, n, chunk)))
+    return int(sum(int((w[s:s + chunk] != 0).sum().item()) for s in range(0, n, chunk)))
+
+
 def _nonzero_chunks(w, chunk=1 << 27):
     """(slot uint32, weight float32) of the non-zero entries of a 1-D tensor/array, scanning in chunks (torch.nonzero
-    refuses tensors with more than INT_MAX elements)."""
+    refuses tensors with more than INT_MAX elements).  For a device tensor only the compacted pairs cross PCIe."""
     idx_parts, val_parts = [], []
     n = w.shape[0]
     is_np = isinstance(w, np.ndarray)
@@ -34,25 +42,30 @@ def _nonzero_chunks(w, chunk=1 << 27):
             val_parts.append(part[nz].astype(np.float32))
         else:
             nz = part.nonzero().squeeze(1)
+            vals = part[nz]
+            # slots < 2^32: ship them as 4-byte integers (bit pattern of uint32 in an int32 tensor for s >= 2^31)
             idx_parts.append((nz + s).cpu().numpy().astype(np.uint32))
-            val_parts.append(part[nz].cpu().numpy().astype(np.float32))
+            val_parts.append(vals.cpu().numpy())
     return (np.concatenate(idx_parts) if idx_parts else np.zeros(0, np.uint32),
             np.concatenate(val_parts) if val_parts else np.zeros(0, np.float32))
 
 
 def save_model(path, w, K, bits, hash_all=False, add_constant=True, clip=True, min_label=-1.0, max_label=1.0):
-    """w: the 2^bits table (numpy float32 or torch tensor, any device)."""
+    """w: the 2^bits table (numpy float32 or torch tensor, any device).  Returns the number of non-zero weights."""
     assert w.shape[0] == (1 << bits)
-    idx, val = _nonzero_chunks(w)
-    nnz = int(idx.size)
+    nnz = _count_nonzero(w)
     dense = nnz * 8 >= (1 << bits) * 4
     flags = int(bool(hash_all)) | (int(bool(add_constant)) << 1) | (int(bool(clip)) << 2)
     with open(path, "wb") as f:
         f.write(_HDR.pack(MAGIC, 1, bits, K, flags, min_label, max_label, nnz, int(dense), 0))
         if dense:
-            arr = w if isinstance(w, np.ndarray) else w.cpu().numpy()
-            np.ascontiguousarray(arr, dtype=np.float32).tofile(f)
+            chunk = 1 << 27                                    # 512 MiB pieces: bounded host memory for 8 GiB tables
+            for s in range(0, w.shape[0], chunk):
+                part = w[s:s + chunk]
+                arr = part if isinstance(part, np.ndarray) else part.cpu().numpy()
+                np.ascontiguousarray(arr, dtype=np.float32).tofile(f)
         else:
+            idx, val = _nonzero_chunks(w)
             idx.tofile(f)
             val.tofile(f)
     return nnz
