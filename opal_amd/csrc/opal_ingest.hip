@@ -235,7 +235,8 @@ __global__ __launch_bounds__(BLOCK) void ing_content_kernel(const uint8_t *__res
 // one wave per record: length, ACGT-only?, output bytes
 __global__ __launch_bounds__(BLOCK) void ing_classify_kernel(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ seq_start,
                                                               uint64_t n_rec, uint64_t total_content,
-                                                              uint32_t *__restrict__ frag_len, uint64_t *__restrict__ rec_bytes)
+                                                              uint32_t *__restrict__ frag_len, uint64_t *__restrict__ rec_bytes,
+                                                              uint64_t *__restrict__ too_long)
 {
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
     const uint64_t nwaves = (uint64_t)gridDim.x * WPB;
@@ -250,7 +251,8 @@ __global__ __launch_bounds__(BLOCK) void ing_classify_kernel(const uint8_t *__re
         }
         const bool acgt = __all(ok);
         if (lane == 0) {
-            const uint32_t l31 = len > 0x7fffffffull ? 0x7fffffffu : (uint32_t)len;   // host rejects longer records
+            if (len > 0x7fffffffull) *too_long = 1;       // reported as OPAL_EINVAL by the host; plain store of a constant
+            const uint32_t l31 = len > 0x7fffffffull ? 0x7fffffffu : (uint32_t)len;
             frag_len[r] = l31 | (acgt ? 0u : OPAL_RAW_FLAG);
             rec_bytes[r] = acgt ? (len + 3) / 4 : len;
         }
@@ -366,6 +368,7 @@ extern "C" int opal_ingest_fasta(opal_ctx *ctx, const uint8_t *d_text, uint64_t 
     St *total_st = (St *)(tile_cnt + ntiles);                    // 16 bytes
     uint64_t *total_cnt = (uint64_t *)(total_st + 1);
     uint64_t *total_out = total_cnt + 1;
+    uint64_t *too_long = total_out + 1;
     uint8_t *seq = (uint8_t *)ctx->ing_seq;
     uint64_t *seq_start = (uint64_t *)ctx->ing_rec;
     uint64_t *rec_bytes = seq_start + (max_records + 1);
@@ -398,15 +401,18 @@ extern "C" int opal_ingest_fasta(opal_ctx *ctx, const uint8_t *d_text, uint64_t 
     *n_records_out = n_rec;
     if (n_rec == 0) return OPAL_OK;
     const int wgrid = (int)std::max<uint64_t>(1, std::min<uint64_t>((n_rec + WPB - 1) / WPB, (uint64_t)ctx->num_cus * 8));
-    hipLaunchKernelGGL(ing_classify_kernel, dim3(wgrid), dim3(BLOCK), 0, st, seq, seq_start, n_rec, T, d_frag_len, rec_bytes);
+    OPAL_HIP_CHECK(ctx, hipMemsetAsync(too_long, 0, sizeof(uint64_t), st));
+    hipLaunchKernelGGL(ing_classify_kernel, dim3(wgrid), dim3(BLOCK), 0, st, seq, seq_start, n_rec, T, d_frag_len, rec_bytes, too_long);
     const uint64_t rt = (n_rec + RS_TILE - 1) / RS_TILE;
     hipLaunchKernelGGL(ing_rec_scan_kernel<false>, dim3((unsigned)rt), dim3(BLOCK), 0, st, rec_bytes, d_frag_len, n_rec, rec_tile_v, out_byte_off, d_frag_off);
     hipLaunchKernelGGL(ing_scan_tiles_u64_kernel, dim3(1), dim3(BLOCK), 0, st, rec_tile_v, rt, total_out);
     hipLaunchKernelGGL(ing_rec_scan_kernel<true>, dim3((unsigned)rt), dim3(BLOCK), 0, st, rec_bytes, d_frag_len, n_rec, rec_tile_v, out_byte_off, d_frag_off);
     OPAL_HIP_CHECK(ctx, hipGetLastError());
-    uint64_t out_bytes = 0;
-    OPAL_HIP_CHECK(ctx, hipMemcpyAsync(&out_bytes, total_out, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    uint64_t tail[2] = {0, 0};   // {packed bytes, any record longer than 2^31-1}
+    OPAL_HIP_CHECK(ctx, hipMemcpyAsync(tail, total_out, sizeof(tail), hipMemcpyDeviceToHost, st));
     OPAL_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    const uint64_t out_bytes = tail[0];
+    if (tail[1]) return opal::fail(ctx, OPAL_EINVAL, "opal_ingest_fasta: a record is longer than 2^31-1 bases");
     if (out_bytes > reads_cap) return opal::fail(ctx, OPAL_ERANGE, "opal_ingest_fasta: d_reads_out too small");
     hipLaunchKernelGGL(ing_pack_kernel, dim3(wgrid), dim3(BLOCK), 0, st, seq, seq_start, d_frag_len, out_byte_off, n_rec, d_reads_out, reads_cap);
     OPAL_HIP_CHECK(ctx, hipGetLastError());

@@ -141,27 +141,41 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
                 }
                 return ok;
             };
+            // Branch-free loads: a load under `if (act[j])` makes the compiler's wait-count pass assume the load may
+            // still be pending when its registers are reused, and it then puts `s_waitcnt vmcnt(0)` in front of every
+            // load of the group (seen in the ISA: the U2 rows were fetched one after the other).  So the grouped paths
+            // load unconditionally (lanes without work read slot 0, an always-cached line), compute on every lane and
+            // predicate only the stores.  The values computed by idle lanes are never stored: their err is 0, so
+            // their update u is 0, and lanes past K never pass `act`.
             // ---- sweep 2: adaptive accumulators + prediction-per-update
             auto adapt_one = [&](uint32_t idx) {
                 const uint32_t row = (idx * Ku) & mask;
                 const bool shared_row = (idx == const_idx) && !ta.sequential;
+                if (shared_row) {   // every example touches the constant row: returning atomics, no lost adds
+#pragma unroll
+                    for (int j = 0; j < NV; j++) {
+                        if (act[j]) {
+                            float *gp = g2 + (size_t)((row + cls[j]) & mask);
+#pragma unroll
+                            for (int e = 0; e < VEC; e++) {
+                                const float gv = atomicAdd(gp + e, gsq[j][e]) + gsq[j][e];
+                                ppu[j][e] += (gv > 0.0f) ? rsq(gv) : 0.0f;
+                            }
+                        }
+                    }
+                    return;
+                }
+                float gv[NV][VEC];
+#pragma unroll
+                for (int j = 0; j < NV; j++) vload<VEC>(g2 + (act[j] ? (size_t)((row + cls[j]) & mask) : (size_t)0), gv[j]);
 #pragma unroll
                 for (int j = 0; j < NV; j++) {
-                    if (act[j]) {
-                        float *gp = g2 + (size_t)((row + cls[j]) & mask);
-                        float gv[VEC];
-                        if (shared_row) {   // every example touches the constant row: returning atomics, no lost adds
 #pragma unroll
-                            for (int e = 0; e < VEC; e++) gv[e] = atomicAdd(gp + e, gsq[j][e]) + gsq[j][e];
-                        } else {
-                            vload<VEC>(gp, gv);
-#pragma unroll
-                            for (int e = 0; e < VEC; e++) gv[e] += gsq[j][e];
-                            vstore<VEC>(gp, gv);
-                        }
-#pragma unroll
-                        for (int e = 0; e < VEC; e++) ppu[j][e] += (gv[e] > 0.0f) ? rsq(gv[e]) : 0.0f;
+                    for (int e = 0; e < VEC; e++) {
+                        gv[j][e] += gsq[j][e];
+                        ppu[j][e] += (gv[j][e] > 0.0f) ? rsq(gv[j][e]) : 0.0f;
                     }
+                    if (act[j]) vstore<VEC>(g2 + (size_t)((row + cls[j]) & mask), gv[j]);
                 }
             };
             if (ta.phases & 1)
@@ -178,22 +192,21 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
                         if (independent(row, idx)) {
                             float gv[U2][NV][VEC];
 #pragma unroll
-                            for (int u = 0; u < U2; u++)
+                            for (int u = 0; u < U2; u++) {
 #pragma unroll
-                                for (int j = 0; j < NV; j++)
-                                    if (act[j]) vload<VEC>(g2 + (size_t)((row[u] + cls[j]) & mask), gv[u][j]);
+                                for (int j = 0; j < NV; j++)   // idle lanes read slot 0 (see the note on branch-free loads)
+                                    vload<VEC>(g2 + (act[j] ? (size_t)((row[u] + cls[j]) & mask) : (size_t)0), gv[u][j]);
+                            }
 #pragma unroll
                             for (int u = 0; u < U2; u++)
 #pragma unroll
                                 for (int j = 0; j < NV; j++) {
-                                    if (act[j]) {
 #pragma unroll
-                                        for (int e = 0; e < VEC; e++) {
-                                            gv[u][j][e] += gsq[j][e];
-                                            ppu[j][e] += (gv[u][j][e] > 0.0f) ? rsq(gv[u][j][e]) : 0.0f;
-                                        }
-                                        vstore<VEC>(g2 + (size_t)((row[u] + cls[j]) & mask), gv[u][j]);
+                                    for (int e = 0; e < VEC; e++) {
+                                        gv[u][j][e] += gsq[j][e];
+                                        ppu[j][e] += (gv[u][j][e] > 0.0f) ? rsq(gv[u][j][e]) : 0.0f;
                                     }
+                                    if (act[j]) vstore<VEC>(g2 + (size_t)((row[u] + cls[j]) & mask), gv[u][j]);
                                 }
                         } else {
 #pragma unroll
@@ -231,25 +244,34 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
             auto update_one = [&](uint32_t idx) {
                 const uint32_t row = (idx * Ku) & mask;
                 const bool shared_row = (idx == const_idx) && !ta.sequential;
+                if (shared_row && !reg) {
 #pragma unroll
-                for (int j = 0; j < NV; j++) {
-                    if (act[j]) {
-                        const size_t slot = (size_t)((row + cls[j]) & mask);
-                        float gv[VEC], d[VEC];
-                        vload<VEC>(g2 + slot, gv);
+                    for (int j = 0; j < NV; j++) {
+                        if (act[j]) {
+                            const size_t slot = (size_t)((row + cls[j]) & mask);
+                            float gv[VEC];
+                            vload<VEC>(g2 + slot, gv);
 #pragma unroll
-                        for (int e = 0; e < VEC; e++) d[e] = (gv[e] > 0.0f) ? upd[j][e] * rsq(gv[e]) : 0.0f;
-                        if (shared_row && !reg) {
-#pragma unroll
-                            for (int e = 0; e < VEC; e++) atomicAdd(w + slot + e, d[e]);
-                        } else {
-                            float wv4[VEC];
-                            vload<VEC>(w + slot, wv4);
-#pragma unroll
-                            for (int e = 0; e < VEC; e++) wv4[e] = finish_w(wv4[e], d[e]);
-                            vstore<VEC>(w + slot, wv4);
+                            for (int e = 0; e < VEC; e++) atomicAdd(w + slot + e, (gv[e] > 0.0f) ? upd[j][e] * rsq(gv[e]) : 0.0f);
                         }
                     }
+                    return;
+                }
+                float gv[NV][VEC], wo[NV][VEC];
+#pragma unroll
+                for (int j = 0; j < NV; j++) {
+                    const size_t slot = act[j] ? (size_t)((row + cls[j]) & mask) : (size_t)0;
+                    vload<VEC>(g2 + slot, gv[j]);
+                    vload<VEC>(w + slot, wo[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < NV; j++) {
+#pragma unroll
+                    for (int e = 0; e < VEC; e++) {
+                        const float d = (gv[j][e] > 0.0f) ? upd[j][e] * rsq(gv[j][e]) : 0.0f;
+                        wo[j][e] = finish_w(wo[j][e], d);
+                    }
+                    if (act[j]) vstore<VEC>(w + (size_t)((row + cls[j]) & mask), wo[j]);
                 }
             };
             if (ta.phases & 2)
@@ -266,27 +288,24 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
                         if (independent(row, idx)) {
                             float gv[U2][NV][VEC], wo[U2][NV][VEC];
 #pragma unroll
-                            for (int u = 0; u < U2; u++)
+                            for (int u = 0; u < U2; u++) {
 #pragma unroll
                                 for (int j = 0; j < NV; j++) {
-                                    if (act[j]) {
-                                        const size_t slot = (size_t)((row[u] + cls[j]) & mask);
-                                        vload<VEC>(g2 + slot, gv[u][j]);
-                                        vload<VEC>(w + slot, wo[u][j]);
-                                    }
+                                    const size_t slot = act[j] ? (size_t)((row[u] + cls[j]) & mask) : (size_t)0;
+                                    vload<VEC>(g2 + slot, gv[u][j]);
+                                    vload<VEC>(w + slot, wo[u][j]);
                                 }
+                            }
 #pragma unroll
                             for (int u = 0; u < U2; u++)
 #pragma unroll
                                 for (int j = 0; j < NV; j++) {
-                                    if (act[j]) {
 #pragma unroll
-                                        for (int e = 0; e < VEC; e++) {
-                                            const float d = (gv[u][j][e] > 0.0f) ? upd[j][e] * rsq(gv[u][j][e]) : 0.0f;
-                                            wo[u][j][e] = finish_w(wo[u][j][e], d);
-                                        }
-                                        vstore<VEC>(w + (size_t)((row[u] + cls[j]) & mask), wo[u][j]);
+                                    for (int e = 0; e < VEC; e++) {
+                                        const float d = (gv[u][j][e] > 0.0f) ? upd[j][e] * rsq(gv[u][j][e]) : 0.0f;
+                                        wo[u][j][e] = finish_w(wo[u][j][e], d);
                                     }
+                                    if (act[j]) vstore<VEC>(w + (size_t)((row[u] + cls[j]) & mask), wo[u][j]);
                                 }
                         } else {
 #pragma unroll
