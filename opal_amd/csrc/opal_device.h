@@ -27,6 +27,7 @@ struct Geom {
     int k, P, t;
     int reverse;
     int hash_all;
+    int p0_run;   // >= 0: pattern 0 is the ascending run p0_run, p0_run+1, ... (Opal's first row is 0..t-1); -1 otherwise
 };
 
 // ------------------------------------------------------------------------------------------ byte helpers
@@ -45,8 +46,10 @@ __device__ __forceinline__ uint32_t rc_byte(uint32_t c)
 // Loads bytes [i0, i0+cnt) of strand `strand` of one fragment into LDS as the ASCII text the reference sees.
 // `shift` (0..3) = position of the fragment's first base inside its first packed byte (packed fragments may start
 // at any base of a packed genome that lives in the same buffer).
+// `codes` (packed fragments only): store the 2-bit code of each base (complemented on the reverse strand) instead
+// of its letter, for the table-driven hash of hash_name_tab.
 __device__ __forceinline__ void load_tile(uint8_t *sq, const uint8_t *src, uint32_t len, bool raw, uint32_t shift,
-                                          int strand, uint32_t i0, uint32_t cnt, int lane)
+                                          int strand, uint32_t i0, uint32_t cnt, int lane, bool codes = false)
 {
     for (uint32_t i = lane; i < cnt; i += WAVE) {
         const uint32_t p = i0 + i;
@@ -57,6 +60,7 @@ __device__ __forceinline__ void load_tile(uint8_t *sq, const uint8_t *src, uint3
         } else {
             const uint32_t q = sp + shift;
             const uint32_t code = (src[q >> 2] >> ((q & 3u) * 2u)) & 3u;
+            if (codes) { sq[i] = (uint8_t)(strand ? 3u - code : code); continue; }
             c = (0x54474341u >> (code * 8u)) & 0xffu;  // "ACGT"
         }
         if (strand) c = rc_byte(c);
@@ -69,7 +73,7 @@ __device__ __forceinline__ void load_tile(uint8_t *sq, const uint8_t *src, uint3
 // descending order for the reverse strand).  abs0 = absolute base offset of the fragment inside `reads`.
 // Bytes of sq at positions >= len receive don't-care values (no window reads them).
 __device__ __forceinline__ void load_strand_packed(uint8_t *sq, const uint8_t *__restrict__ reads, uint64_t reads_bytes,
-                                                   uint64_t abs0, uint32_t len, int strand, int lane)
+                                                   uint64_t abs0, uint32_t len, int strand, int lane, bool codes)
 {
     uint32_t *sq4 = reinterpret_cast<uint32_t *>(sq);
     const int64_t last_byte = (int64_t)reads_bytes - 1;
@@ -87,9 +91,9 @@ __device__ __forceinline__ void load_strand_packed(uint8_t *sq, const uint8_t *_
         uint32_t chars;
         if (strand) {
             sel = __builtin_amdgcn_perm(0u, sel, 0x00010203u);         // reverse the 4 bases
-            chars = __builtin_amdgcn_perm(0u, 0x41434754u, sel);       // "TGCA"[code] = complement
+            chars = codes ? (sel ^ 0x03030303u) : __builtin_amdgcn_perm(0u, 0x41434754u, sel);   // "TGCA"[code] = complement
         } else {
-            chars = __builtin_amdgcn_perm(0u, 0x54474341u, sel);       // "ACGT"[code]
+            chars = codes ? sel : __builtin_amdgcn_perm(0u, 0x54474341u, sel);                    // "ACGT"[code]
         }
         sq4[i] = chars;
     }
@@ -126,6 +130,15 @@ __device__ __forceinline__ uint32_t mm_k(uint32_t k1)
     k1 *= 0x1b873593u;
     return k1;
 }
+// block step with the block's term mm_k(k1) already known
+__device__ __forceinline__ uint32_t mm_hk(uint32_t h, uint32_t km)
+{
+    h ^= km;
+    h = rotl32(h, 13);
+    uint32_t h5;
+    asm("v_lshl_add_u32 %0, %1, 2, %1" : "=v"(h5) : "v"(h));
+    return h5 + 0xe6546b64u;
+}
 __device__ __forceinline__ uint32_t mm_h(uint32_t h, uint32_t k1)
 {
     h ^= mm_k(k1);
@@ -146,24 +159,64 @@ __device__ __forceinline__ uint32_t mm_fin(uint32_t h, uint32_t len)
     return h;
 }
 
-// Hash of the feature name "<t gathered chars><decimal p>" (util/fasta2skm.py:140) for window base `wb`
-// (LDS pointer to the window's first byte).  T > 0: t known at compile time (fully unrolled), p < 10.
+// Hash of the feature name "<t gathered chars><decimal p>" (util/fasta2skm.py:140) for the window whose first
+// byte in LDS is `wb`.
+// Table-driven variant for 2-bit packed fragments (letters are only ACGT): a block of 4 gathered letters has 256
+// possible values, so its murmur term mm_k(4 letters) = two quarter-rate 32-bit multiplies + a rotate comes from a
+// 256-entry LDS table (one per block) indexed by the 4 gathered 2-bit codes (the emit kernel is VALU-bound: PMC
+// shows every SIMD issue cycle taken, profiles/r01_cfg5_emit).  wb points at staged CODES (load_* with codes=true).
+constexpr int KTAB = 256;
+__device__ __forceinline__ void fill_kmer4_table(uint32_t *tab)   // one table per block; every thread calls it once
+{
+    for (uint32_t i = threadIdx.x; i < (uint32_t)KTAB; i += BLOCK) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) word |= ((0x54474341u >> (((i >> (2 * j)) & 3u) * 8u)) & 0xffu) << (8 * j);   // "ACGT"[code j]
+        tab[i] = mm_k(word);
+    }
+    __syncthreads();
+}
+// pq[b] = the 4 positions of block b, one per byte (the pattern row read as dwords; wave-uniform, kept in SGPRs)
 template <int T>
-__device__ __forceinline__ uint32_t hash_name_fast(const uint8_t *wb, const uint8_t *__restrict__ pp, int p)
+__device__ __forceinline__ uint32_t hash_name_tab(const uint8_t *wb, const uint32_t (&pq)[T / 4], int p, const uint32_t *tab)
 {
     static_assert(T % 4 == 0, "fast path needs whole blocks");
     uint32_t h = 0;
-    // pp is wave-uniform and 4-byte aligned (T % 4 == 0, table base from hipMalloc): one scalar dword per block
-    const uint32_t *__restrict__ pw = reinterpret_cast<const uint32_t *>(pp);
 #pragma unroll
     for (int b = 0; b < T / 4; b++) {
-        const uint32_t q = pw[b];
-        const uint32_t k1 = (uint32_t)wb[q & 0xffu] | ((uint32_t)wb[(q >> 8) & 0xffu] << 8) |
-                            ((uint32_t)wb[(q >> 16) & 0xffu] << 16) | ((uint32_t)wb[q >> 24] << 24);
-        h = mm_h(h, k1);
+        const uint32_t q = pq[b];
+        const uint32_t idx = (uint32_t)wb[q & 0xffu] | ((uint32_t)wb[(q >> 8) & 0xffu] << 2) |
+                             ((uint32_t)wb[(q >> 16) & 0xffu] << 4) | ((uint32_t)wb[q >> 24] << 6);
+        h = mm_hk(h, tab[idx]);
     }
     h ^= mm_k((uint32_t)('0' + p));
     return mm_fin(h, T + 1);
+}
+
+// A pattern made of consecutive positions needs no gather: cw[i] holds the codes of bases i..i+3 packed into one
+// byte (= the table index of the block that starts at base i), so a block costs one ds_read_u8 with an immediate
+// offset and one table read.  wbw = cw + window base + first position of the run.
+template <int T>
+__device__ __forceinline__ uint32_t hash_name_run(const uint8_t *wbw, int p, const uint32_t *tab)
+{
+    uint32_t h = 0;
+#pragma unroll
+    for (int b = 0; b < T / 4; b++) h = mm_hk(h, tab[wbw[4 * b]]);
+    h ^= mm_k((uint32_t)('0' + p));
+    return mm_fin(h, T + 1);
+}
+// cw[i] = c[i] | c[i+1]<<2 | c[i+2]<<4 | c[i+3]<<6 for the staged code bytes c[0..len) of one strand (both arrays
+// SEQB/2 bytes, 4-byte aligned); entries whose block would pass the end of the strand are don't-care.
+__device__ __forceinline__ void pack_code_windows(uint8_t *cw, const uint8_t *c, uint32_t len, int lane)
+{
+    const uint32_t *c4 = reinterpret_cast<const uint32_t *>(c);
+    uint32_t *w4 = reinterpret_cast<uint32_t *>(cw);
+    constexpr uint32_t LAST = SEQB / 8 - 1;
+    auto squeeze = [](uint32_t d) { return (d | (d >> 6) | (d >> 12) | (d >> 18)) & 0xffu; };   // 4 code bytes -> 8 bits
+    for (uint32_t m = lane; m < (len + 3u) / 4u; m += WAVE) {
+        const uint32_t x = squeeze(c4[m]) | (squeeze(c4[min(m + 1u, LAST)]) << 8);             // codes 4m .. 4m+7
+        w4[m] = (x & 0xffu) | (((x >> 2) & 0xffu) << 8) | (((x >> 4) & 0xffu) << 16) | (((x >> 6) & 0xffu) << 24);
+    }
 }
 
 // Generic: any t, any p < 1000, optional VW `--hash strings` digit rule (all-digit names are numbers).
@@ -195,10 +248,12 @@ __device__ __forceinline__ uint32_t hash_name_generic(const uint8_t *wb, const u
 // ------------------------------------------------------------------------------------------ phase H
 // Walks one fragment, appending masked hashes to the LDS buffer hb; calls flush(count) whenever the buffer
 // is full and once at the end (after the optional constant feature).  flush must consume hb[0..count).
+// sq: 2*SEQB bytes of wave-private LDS (staged strands, then the packed code windows of pack_code_windows);
+// tab: the block's table of fill_kmer4_table.
 template <class Flush>
 __device__ __forceinline__ void walk_fragment(const Batch &B, const Geom &G, uint64_t frag, uint32_t mask,
-                                              bool add_const, uint32_t const_idx, uint8_t *sq, uint32_t *hb, int lane,
-                                              Flush &&flush)
+                                              bool add_const, uint32_t const_idx, uint8_t *sq, uint32_t *hb,
+                                              const uint32_t *tab, int lane, Flush &&flush)
 {
     const FragRef fr = locate_fragment(B, frag);  // never reads outside the batch buffer
     const bool raw = fr.raw;
@@ -210,15 +265,25 @@ __device__ __forceinline__ void walk_fragment(const Batch &B, const Geom &G, uin
     uint32_t fill = 0;
     const uint32_t S = G.reverse ? 2u : 1u;
     // hashes `cnt` windows whose LDS start is base_of(local index) and appends them at hb[fill + local*P + p]
-    auto hash_windows = [&](uint32_t cnt, auto &&base_of) {
+    auto hash_windows = [&](uint32_t cnt, bool have_cw, auto &&base_of) {
         for (int p = 0; p < P; p++) {
             const uint8_t *pp = G.pos + p * t;
-            for (uint32_t wl = lane; wl < cnt; wl += WAVE) {
-                const uint8_t *wb = sq + base_of(wl);
-                uint32_t h;
-                if (fast16) h = hash_name_fast<16>(wb, pp, p) & mask;
-                else h = hash_name_generic(wb, pp, t, p, digit_rule, mask);
-                hb[fill + wl * (uint32_t)P + (uint32_t)p] = h;
+            if (p == 0 && have_cw) {
+                const uint8_t *cw = sq + SEQB + G.p0_run;
+                for (uint32_t wl = lane; wl < cnt; wl += WAVE)
+                    hb[fill + wl * (uint32_t)P] = hash_name_run<16>(cw + base_of(wl), 0, tab) & mask;
+            } else if (fast16) {
+                // the pattern row as 4 dwords, read once per pattern into SGPRs (left to the compiler this became a
+                // vector global load + vmcnt(0) inside the window loop)
+                uint32_t pq[4];
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                    pq[b] = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint32_t *>(pp)[b]);
+                for (uint32_t wl = lane; wl < cnt; wl += WAVE)
+                    hb[fill + wl * (uint32_t)P + (uint32_t)p] = hash_name_tab<16>(sq + base_of(wl), pq, p, tab) & mask;
+            } else {
+                for (uint32_t wl = lane; wl < cnt; wl += WAVE)
+                    hb[fill + wl * (uint32_t)P + (uint32_t)p] = hash_name_generic(sq + base_of(wl), pp, t, p, digit_rule, mask);
             }
         }
         // wave-private LDS: every lane's ds_write retires before the next ds_read issues (same wave, in-order
@@ -237,18 +302,25 @@ __device__ __forceinline__ void walk_fragment(const Batch &B, const Geom &G, uin
                 load_tile(sq, src, len, raw, fr.shift, 0, 0, len, lane);
                 if (S == 2) load_tile(sq + LP, src, len, raw, fr.shift, 1, 0, len, lane);
             } else {
-                load_strand_packed(sq, B.reads, B.reads_bytes, B.off[frag], len, 0, lane);
-                if (S == 2) load_strand_packed(sq + LP, B.reads, B.reads_bytes, B.off[frag], len, 1, lane);
+                load_strand_packed(sq, B.reads, B.reads_bytes, B.off[frag], len, 0, lane, fast16);
+                if (S == 2) load_strand_packed(sq + LP, B.reads, B.reads_bytes, B.off[frag], len, 1, lane, fast16);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const bool have_cw = fast16 && G.p0_run >= 0;
+            if (have_cw) {
+                pack_code_windows(sq + SEQB, sq, len, lane);
+                if (S == 2) pack_code_windows(sq + SEQB + LP, sq + LP, len, lane);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
             const uint32_t U = S * W;
             uint32_t u0 = 0;
             while (u0 < U) {
                 uint32_t room = (HB - fill) / (uint32_t)P;
                 if (room < min(U - u0, (uint32_t)WAVE)) { flush(fill); fill = 0; room = HB / (uint32_t)P; }
                 const uint32_t tu = min(U - u0, room);
-                hash_windows(tu, [&](uint32_t ul) { const uint32_t u = u0 + ul; return u < W ? u : LP + (u - W); });
+                hash_windows(tu, have_cw, [&](uint32_t ul) { const uint32_t u = u0 + ul; return u < W ? u : LP + (u - W); });
                 u0 += tu;
             }
         } else {
@@ -259,10 +331,10 @@ __device__ __forceinline__ void walk_fragment(const Batch &B, const Geom &G, uin
                     uint32_t room = (HB - fill) / (uint32_t)P;
                     if (room < min(W - w0, (uint32_t)WAVE)) { flush(fill); fill = 0; room = HB / (uint32_t)P; }
                     const uint32_t tw = min(min(W - w0, tw_seq), room);
-                    load_tile(sq, src, len, raw, fr.shift, (int)s, w0, tw + (uint32_t)k - 1u, lane);
+                    load_tile(sq, src, len, raw, fr.shift, (int)s, w0, tw + (uint32_t)k - 1u, lane, fast16);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    hash_windows(tw, [&](uint32_t wl) { return wl; });
+                    hash_windows(tw, false, [&](uint32_t wl) { return wl; });
                     w0 += tw;
                 }
             }

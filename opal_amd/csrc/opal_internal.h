@@ -13,6 +13,7 @@ struct opal_ctx {
     // patterns (util/fasta2skm.py:120-134)
     int k = 0, P = 0, t = 0;
     uint8_t *d_pos = nullptr;  // P*t positions, each < k <= 256
+    int p0_run = -1;           // first position of pattern 0 when it is a run of consecutive positions, else -1
     // weights (VW regressor, compact `w` components)
     float *d_w = nullptr;      // 2^bits + pad floats: first K(+3) floats mirrored at the end so rows never wrap
     uint64_t w_alloc_floats = 0;

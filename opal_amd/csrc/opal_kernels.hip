@@ -29,15 +29,17 @@ namespace {
 __global__ __launch_bounds__(BLOCK) void emit_idx_kernel(Batch B, Geom G, uint32_t mask, const uint64_t *__restrict__ out_off,
                                                           uint32_t *__restrict__ out_idx)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_seq[WPB][SEQB];
+    __shared__ __attribute__((aligned(16))) uint8_t s_seq[WPB][2 * SEQB];
     __shared__ __attribute__((aligned(16))) uint32_t s_hb[WPB][HB + HB_PAD];
+    __shared__ uint32_t s_tab[KTAB];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = threadIdx.x / WAVE;
+    fill_kmer4_table(s_tab);
     const uint64_t nwaves = (uint64_t)gridDim.x * WPB;
     for (uint64_t frag = (uint64_t)blockIdx.x * WPB + wv; frag < B.n; frag += nwaves) {
         uint32_t *dst = out_idx + out_off[frag];
         uint32_t *hb = s_hb[wv];
-        walk_fragment(B, G, frag, mask, false, 0u, s_seq[wv], hb, lane, [&](uint32_t cnt) {
+        walk_fragment(B, G, frag, mask, false, 0u, s_seq[wv], hb, s_tab, lane, [&](uint32_t cnt) {
             if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {   // wave-uniform: 16-byte stores, then the tail
                 const uint32_t n4 = cnt / 4u;
                 for (uint32_t i = lane; i < n4; i += WAVE)
@@ -99,10 +101,12 @@ __global__ __launch_bounds__(BLOCK) void predict_kernel(Batch B, Geom G, const f
 {
     using V = typename VecOf<VEC>::type;
     constexpr int CH = WAVE * VEC * NV;  // classes per chunk
-    __shared__ __attribute__((aligned(16))) uint8_t s_seq[WPB][SEQB];
+    __shared__ __attribute__((aligned(16))) uint8_t s_seq[WPB][2 * SEQB];
     __shared__ __attribute__((aligned(16))) uint32_t s_hb[WPB][HB + HB_PAD];
+    __shared__ uint32_t s_tab[KTAB];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = threadIdx.x / WAVE;
+    fill_kmer4_table(s_tab);
     uint32_t *hb = s_hb[wv];
     const uint64_t nwaves = (uint64_t)gridDim.x * WPB;
     const uint32_t Ku = (uint32_t)K;
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(BLOCK) void predict_kernel(Batch B, Geom G, const f
             V acc[NV];
 #pragma unroll
             for (int j = 0; j < NV; j++) acc[j] = V{};
-            walk_fragment(B, G, frag, mask, add_constant != 0, const_idx, s_seq[wv], hb, lane, [&](uint32_t cnt) {
+            walk_fragment(B, G, frag, mask, add_constant != 0, const_idx, s_seq[wv], hb, s_tab, lane, [&](uint32_t cnt) {
                 // dummy rows for the prefetch overrun: the constant row (always cache-hot)
                 if (lane < HB_PAD) hb[cnt + lane] = const_idx;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -375,6 +379,9 @@ extern "C" int opal_set_patterns(opal_ctx *ctx, const int32_t *pos, int P, int t
     OPAL_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_pos, h.size()));
     OPAL_HIP_CHECK(ctx, hipMemcpy(ctx->d_pos, h.data(), h.size(), hipMemcpyHostToDevice));
     ctx->P = P; ctx->t = t; ctx->k = k;
+    ctx->p0_run = pos[0];   // pattern 0 as a run of consecutive positions (Opal's first row: ldpc.py:83-85), else -1
+    for (int j = 1; j < t; j++)
+        if (pos[j] != pos[0] + j) ctx->p0_run = -1;
     return OPAL_OK;
 }
 
@@ -477,7 +484,7 @@ extern "C" int opal_features(opal_ctx *ctx, const uint8_t *d_reads, uint64_t rea
     if (n == 0) return OPAL_OK;
     OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     Batch B{d_reads, reads_bytes, d_frag_off, d_frag_len, n};
-    Geom G{ctx->d_pos, ctx->k, ctx->P, ctx->t, reverse != 0, ctx->hash_all};
+    Geom G{ctx->d_pos, ctx->k, ctx->P, ctx->t, reverse != 0, ctx->hash_all, ctx->p0_run};
     const uint32_t mask = bits == 32 ? 0xffffffffu : ((1u << bits) - 1u);
     int grid = 1;
     rc = grid_for(ctx, (const void *)&emit_idx_kernel, n, &grid);
@@ -497,7 +504,7 @@ extern "C" int opal_feature_names(opal_ctx *ctx, const uint8_t *d_reads, uint64_
     if (n == 0) return OPAL_OK;
     OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     Batch B{d_reads, reads_bytes, d_frag_off, d_frag_len, n};
-    Geom G{ctx->d_pos, ctx->k, ctx->P, ctx->t, reverse != 0, ctx->hash_all};
+    Geom G{ctx->d_pos, ctx->k, ctx->P, ctx->t, reverse != 0, ctx->hash_all, ctx->p0_run};
     int grid = 1;
     rc = grid_for(ctx, (const void *)&emit_names_kernel, n, &grid);
     if (rc) return rc;
@@ -522,7 +529,7 @@ extern "C" int opal_predict(opal_ctx *ctx, const uint8_t *d_reads, uint64_t read
     if (n == 0) return OPAL_OK;
     OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     Batch B{d_reads, reads_bytes, d_frag_off, d_frag_len, n};
-    Geom G{ctx->d_pos, ctx->k, ctx->P, ctx->t, reverse != 0, ctx->hash_all};
+    Geom G{ctx->d_pos, ctx->k, ctx->P, ctx->t, reverse != 0, ctx->hash_all, ctx->p0_run};
     const uint32_t mask = ctx->bits == 32 ? 0xffffffffu : ((1u << ctx->bits) - 1u);
     const uint32_t const_idx = OPAL_VW_CONSTANT & mask;
     const Variant &v = pick_variant(ctx->K);

@@ -56,10 +56,12 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
 {
     using V = typename VecOf<VEC>::type;
     constexpr int CH = WAVE * VEC * NV;
-    __shared__ __attribute__((aligned(16))) uint8_t s_seq[WPB][SEQB];
+    __shared__ __attribute__((aligned(16))) uint8_t s_seq[WPB][2 * SEQB];
     __shared__ __attribute__((aligned(16))) uint32_t s_hb[WPB][HB + HB_PAD];
+    __shared__ uint32_t s_tab[KTAB];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = threadIdx.x / WAVE;
+    fill_kmer4_table(s_tab);
     uint32_t *hb = s_hb[wv];
     uint64_t nwaves = (uint64_t)gridDim.x * WPB;
     uint64_t first = (uint64_t)blockIdx.x * WPB + wv;
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
 #pragma unroll
             for (int j = 0; j < NV; j++) acc[j] = V{};
             uint32_t nfeat = 0;
-            walk_fragment(B, G, frag, mask, true, const_idx, s_seq[wv], hb, lane, [&](uint32_t cnt) {
+            walk_fragment(B, G, frag, mask, true, const_idx, s_seq[wv], hb, s_tab, lane, [&](uint32_t cnt) {
                 if (lane < HB_PAD) hb[cnt + lane] = const_idx;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
                 }
             };
             if (ta.phases & 1)
-            walk_fragment(B, G, frag, mask, true, const_idx, s_seq[wv], hb, lane, [&](uint32_t cnt) {
+            walk_fragment(B, G, frag, mask, true, const_idx, s_seq[wv], hb, s_tab, lane, [&](uint32_t cnt) {
                 uint32_t f = 0;
                 if constexpr (U2 > 1) {
                     for (; f + U2 <= cnt; f += U2) {
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
                 }
             };
             if (ta.phases & 2)
-            walk_fragment(B, G, frag, mask, true, const_idx, s_seq[wv], hb, lane, [&](uint32_t cnt) {
+            walk_fragment(B, G, frag, mask, true, const_idx, s_seq[wv], hb, s_tab, lane, [&](uint32_t cnt) {
                 uint32_t f = 0;
                 if constexpr (U2 > 1) {
                     for (; f + U2 <= cnt; f += U2) {
@@ -425,7 +427,7 @@ extern "C" int opal_train_batch(opal_ctx *ctx, const uint8_t *d_reads, uint64_t 
     if (n == 0) return OPAL_OK;
     OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     Batch B{d_reads, reads_bytes, d_frag_off, d_frag_len, n};
-    Geom G{ctx->d_pos, ctx->k, ctx->P, ctx->t, reverse != 0, ctx->hash_all};
+    Geom G{ctx->d_pos, ctx->k, ctx->P, ctx->t, reverse != 0, ctx->hash_all, ctx->p0_run};
     const uint32_t mask = ctx->bits == 32 ? 0xffffffffu : ((1u << ctx->bits) - 1u);
     const uint32_t const_idx = OPAL_VW_CONSTANT & mask;
     const TVariant &v = pick_train_variant(ctx->K);
