@@ -404,6 +404,32 @@ def test_randomised_geometries_against_oracle(amd, eng, oracle):
     eng.set_vw_options()
 
 
+def test_run_patterns_and_unsorted_rows_against_oracle(amd, eng, oracle):
+    """The t=16 fast paths: pattern 0 as a run of consecutive positions starting anywhere in the window (gather-free
+    path), the identity pattern used without a pattern file (k = t = 16, fasta2skm.py:130-132), a run that is NOT
+    row 0, and rows whose positions are not ascending (the name keeps the file's order, fasta2skm.py:127-129)."""
+    rng = np.random.default_rng(5150)
+    cases = []
+    for start in (0, 1, 3, 47, 48):
+        rows = [np.arange(start, start + 16)] + [np.sort(rng.choice(64, size=16, replace=False)) for _ in range(2)]
+        cases.append((64, np.stack(rows)))
+    cases.append((16, np.arange(16)[None, :]))                                             # identity, P = 1
+    cases.append((64, np.stack([np.sort(rng.choice(64, size=16, replace=False)), np.arange(8, 24)])))   # run in row 1 only
+    cases.append((64, np.stack([rng.permutation(64)[:16], np.arange(16)[::-1]])))          # unsorted rows
+    cases.append((240, np.stack([np.arange(224, 240), np.sort(rng.choice(240, size=16, replace=False))])))
+    for k, pos in cases:
+        pos = pos.astype(np.int32)
+        eng.set_patterns(pos, k)
+        lens = [0, k - 1, k, k + 1, k + 62, k + 63, k + 64, 199, 200, 255, 256, 257, 300, 1000]
+        seqs = [bytes(rng.choice(ACGT, size=L)) for L in lens] + [b"ACGTNNNNacgt" * 30, b"acgt" * 70]
+        for reverse in (False, True):
+            batch = eng.upload(amd.PackedReads.from_sequences(seqs))
+            idx, off = eng.features(batch, reverse, 31)
+            oidx, ooff = oracle.features_batch(seqs, k, pos, reverse, 31)
+            assert np.array_equal(off.cpu().numpy().view(np.uint64), ooff), (k, pos[0, 0], reverse)
+            assert np.array_equal(_u32(idx), oidx), (k, pos[0, 0], reverse)
+
+
 def test_randomised_predict_switches_against_oracle(amd, eng, oracle):
     rng = np.random.default_rng(77001)
     for trial in range(40):
