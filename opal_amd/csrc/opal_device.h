@@ -23,8 +23,8 @@ struct Batch {
     uint64_t n;
 };
 struct Geom {
-    const uint8_t *pos;  // P*t
-    int k, P, t;
+    const uint8_t *pos;  // P rows of ts bytes: t positions, padded to a multiple of 4 so a row reads as dwords
+    int k, P, t, ts;
     int reverse;
     int hash_all;
     int p0_run;   // >= 0: pattern 0 is the ascending run p0_run, p0_run+1, ... (Opal's first row is 0..t-1); -1 otherwise
@@ -235,7 +235,15 @@ __device__ __forceinline__ uint32_t hash_name_generic(const uint8_t *wb, const u
         digits = digits && (d <= 9u);
         num = num * 10ull + d;
     };
-    for (int j = 0; j < t; j++) feed(wb[pp[j]]);
+    // the row as dwords: wave-uniform, so the position bytes come from the scalar unit (a byte load of the same
+    // address is a vector load + vmcnt(0) in front of every character)
+    const uint32_t *__restrict__ pw = reinterpret_cast<const uint32_t *>(pp);
+    uint32_t q = 0;
+    for (int j = 0; j < t; j++) {
+        if ((j & 3) == 0) q = (uint32_t)__builtin_amdgcn_readfirstlane((int)pw[j >> 2]);
+        feed(wb[q & 0xffu]);
+        q >>= 8;
+    }
     if (p >= 100) feed('0' + (p / 100) % 10);
     if (p >= 10) feed('0' + (p / 10) % 10);
     feed('0' + p % 10);
@@ -267,7 +275,7 @@ __device__ __forceinline__ void walk_fragment(const Batch &B, const Geom &G, uin
     // hashes `cnt` windows whose LDS start is base_of(local index) and appends them at hb[fill + local*P + p]
     auto hash_windows = [&](uint32_t cnt, bool have_cw, auto &&base_of) {
         for (int p = 0; p < P; p++) {
-            const uint8_t *pp = G.pos + p * t;
+            const uint8_t *pp = G.pos + p * G.ts;
             if (p == 0 && have_cw) {
                 const uint8_t *cw = sq + SEQB + G.p0_run;
                 for (uint32_t wl = lane; wl < cnt; wl += WAVE)

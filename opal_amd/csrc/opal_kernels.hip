@@ -83,7 +83,7 @@ __global__ __launch_bounds__(BLOCK) void emit_names_kernel(Batch B, Geom G, cons
                 for (uint32_t i = lane; i < tw * (uint32_t)P; i += WAVE) {
                     const uint32_t wl = i / (uint32_t)P, p = i % (uint32_t)P;
                     uint8_t *o = out_names + (f0 + i) * (uint64_t)t;
-                    for (int j = 0; j < t; j++) o[j] = sq[wl + G.pos[p * (uint32_t)t + j]];
+                    for (int j = 0; j < t; j++) o[j] = sq[wl + G.pos[p * (uint32_t)G.ts + j]];
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -368,10 +368,11 @@ extern "C" int opal_set_patterns(opal_ctx *ctx, const int32_t *pos, int P, int t
     // the reference only asserts k % t == 0 when a pattern file exists (fasta2skm.py:125); the identity
     // pattern used without a file has t == k, which satisfies it too.
     if (k % t != 0) return opal::fail(ctx, OPAL_EINVAL, "opal_set_patterns: k must be a multiple of t");
-    std::vector<uint8_t> h((size_t)P * t);
+    const int ts = (t + 3) & ~3;   // device rows are padded to whole dwords (Geom::ts)
+    std::vector<uint8_t> h((size_t)P * ts, 0);
     for (int i = 0; i < P * t; i++) {
         if (pos[i] < 0 || pos[i] >= k) return opal::fail(ctx, OPAL_EINVAL, "opal_set_patterns: position outside [0,k)");
-        h[i] = (uint8_t)pos[i];
+        h[(size_t)(i / t) * ts + (i % t)] = (uint8_t)pos[i];
     }
     OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     OPAL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -484,7 +485,7 @@ extern "C" int opal_features(opal_ctx *ctx, const uint8_t *d_reads, uint64_t rea
     if (n == 0) return OPAL_OK;
     OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     Batch B{d_reads, reads_bytes, d_frag_off, d_frag_len, n};
-    Geom G{ctx->d_pos, ctx->k, ctx->P, ctx->t, reverse != 0, ctx->hash_all, ctx->p0_run};
+    Geom G{ctx->d_pos, ctx->k, ctx->P, ctx->t, (ctx->t + 3) & ~3, reverse != 0, ctx->hash_all, ctx->p0_run};
     const uint32_t mask = bits == 32 ? 0xffffffffu : ((1u << bits) - 1u);
     int grid = 1;
     rc = grid_for(ctx, (const void *)&emit_idx_kernel, n, &grid);
@@ -504,7 +505,7 @@ extern "C" int opal_feature_names(opal_ctx *ctx, const uint8_t *d_reads, uint64_
     if (n == 0) return OPAL_OK;
     OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     Batch B{d_reads, reads_bytes, d_frag_off, d_frag_len, n};
-    Geom G{ctx->d_pos, ctx->k, ctx->P, ctx->t, reverse != 0, ctx->hash_all, ctx->p0_run};
+    Geom G{ctx->d_pos, ctx->k, ctx->P, ctx->t, (ctx->t + 3) & ~3, reverse != 0, ctx->hash_all, ctx->p0_run};
     int grid = 1;
     rc = grid_for(ctx, (const void *)&emit_names_kernel, n, &grid);
     if (rc) return rc;
@@ -529,7 +530,7 @@ extern "C" int opal_predict(opal_ctx *ctx, const uint8_t *d_reads, uint64_t read
     if (n == 0) return OPAL_OK;
     OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     Batch B{d_reads, reads_bytes, d_frag_off, d_frag_len, n};
-    Geom G{ctx->d_pos, ctx->k, ctx->P, ctx->t, reverse != 0, ctx->hash_all, ctx->p0_run};
+    Geom G{ctx->d_pos, ctx->k, ctx->P, ctx->t, (ctx->t + 3) & ~3, reverse != 0, ctx->hash_all, ctx->p0_run};
     const uint32_t mask = ctx->bits == 32 ? 0xffffffffu : ((1u << ctx->bits) - 1u);
     const uint32_t const_idx = OPAL_VW_CONSTANT & mask;
     const Variant &v = pick_variant(ctx->K);

@@ -427,7 +427,7 @@ extern "C" int opal_train_batch(opal_ctx *ctx, const uint8_t *d_reads, uint64_t 
     if (n == 0) return OPAL_OK;
     OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     Batch B{d_reads, reads_bytes, d_frag_off, d_frag_len, n};
-    Geom G{ctx->d_pos, ctx->k, ctx->P, ctx->t, reverse != 0, ctx->hash_all, ctx->p0_run};
+    Geom G{ctx->d_pos, ctx->k, ctx->P, ctx->t, (ctx->t + 3) & ~3, reverse != 0, ctx->hash_all, ctx->p0_run};
     const uint32_t mask = ctx->bits == 32 ? 0xffffffffu : ((1u << ctx->bits) - 1u);
     const uint32_t const_idx = OPAL_VW_CONSTANT & mask;
     const TVariant &v = pick_train_variant(ctx->K);
