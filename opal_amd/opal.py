@@ -57,6 +57,32 @@ def vw_class_to_taxid(inputfile, dicofile, outputfile):
         dst.writelines(by_class[str(int(float(ln.strip())))] + "\n" for ln in src)
 
 
+def _write_lines(path, table, idx, chunk=8_000_000):
+    """Writes table[idx[i]] + newline for every i at C speed: a fixed-width byte table is gathered with numpy and the
+    NUL padding is dropped from the byte stream (entries never contain NUL)."""
+    with open(path, "wb") as dst:
+        for a in range(0, idx.shape[0], chunk):
+            dst.write(table[idx[a:a + chunk]].tobytes().replace(b"\0", b""))
+
+
+def write_predictions(classes, dicofile, pred_file, taxid_file):
+    """What `vw -p` followed by vw_class_to_taxid leave on disk (reference opal.py:449-451,484 and :76-88), written
+    straight from the class-id array: `pred_file` one class id per line, `taxid_file` the taxid of each through
+    vw-dico.txt.  A class the dico does not hold raises KeyError, as in the reference."""
+    classes = np.ascontiguousarray(classes, dtype=np.int64)
+    with open(dicofile) as fh:
+        by_class = {int(cols[1]): cols[0] for cols in (ln.strip().split()[:2] for ln in fh if ln.strip())}
+    top = int(classes.max()) if classes.size else 0
+    present = np.unique(classes)
+    for c in present.tolist():
+        if c not in by_class:
+            raise KeyError(str(c))
+    ids = np.array([("%d\n" % c).encode() for c in range(top + 1)], dtype="S")
+    tax = np.array([(by_class.get(c, "") + "\n").encode("latin-1") for c in range(top + 1)], dtype="S")
+    _write_lines(pred_file, ids, classes)
+    _write_lines(taxid_file, tax, classes)
+
+
 def get_fasta_and_taxid(directory):
     """[first *.fasta of the directory, its same-named .taxid]; RuntimeError when either is missing
     (reference opal.py:90-100)."""
@@ -300,9 +326,7 @@ def predict(model_dir, test_dir, predict_dir, args, engine=None, chunk=2_000_000
         with open(prefix + "_vwps.log", "w") as log:
             log.write("opal_amd scorer: %d fragments, oaa=%d bits=%d, kernel %s, %d rank(s)\n" % (
                 n_frag, hdr["K"], hdr["bits"], eng.predict_kernel_name(), world))
-        with open(prediction_file, "w") as f:                # what `vw -p` writes: one class id per line
-            f.write("".join("%d\n" % c for c in full.tolist()))
-        vw_class_to_taxid(prediction_file, dico, prefix + '.preds.taxid')
+        write_predictions(full, dico, prediction_file, prefix + '.preds.taxid')   # `vw -p` file + vw_class_to_taxid
         print("------------------------------------------------\nPredicted labels:   {}\nTotal wall clock runtime (sec): {}\n"
               "================================================".format(prefix + '.preds.taxid', (datetime.now() - starttime).total_seconds()))
         sys.stdout.flush()

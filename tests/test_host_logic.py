@@ -182,3 +182,20 @@ def test_cli_parser_matches_reference_defaults():
         opal.train(d, os.path.join(d, "m"), ns)
     with pytest.raises(RuntimeError):                    # reference opal.py:93-96
         opal.get_fasta_and_taxid(tempfile.mkdtemp())
+
+
+def test_write_predictions_equals_reference_style_files(tmp_path):
+    """write_predictions (array -> `vw -p` file + taxid file) leaves the same bytes as the reference's two steps
+    (opal.py:449-451 then vw_class_to_taxid, opal.py:76-88), including the KeyError for a class outside the dico."""
+    from opal_amd import opal
+    dico = tmp_path / "vw-dico.txt"
+    dico.write_text("".join("%s\t%d\n" % (name, c) for c, name in enumerate(["562", "1280", "NC_000913.3", "9"], start=1)))
+    cls = np.array([3, 1, 1, 4, 2, 3, 3], dtype=np.int32)
+    opal.write_predictions(cls, str(dico), str(tmp_path / "p.vw"), str(tmp_path / "p.taxid"))
+    assert (tmp_path / "p.vw").read_text() == "3\n1\n1\n4\n2\n3\n3\n"
+    opal.vw_class_to_taxid(str(tmp_path / "p.vw"), str(dico), str(tmp_path / "ref.taxid"))
+    assert (tmp_path / "p.taxid").read_bytes() == (tmp_path / "ref.taxid").read_bytes()
+    with pytest.raises(KeyError):
+        opal.write_predictions(np.array([1, 5]), str(dico), str(tmp_path / "q.vw"), str(tmp_path / "q.taxid"))
+    opal.write_predictions(np.zeros(0, dtype=np.int32), str(dico), str(tmp_path / "e.vw"), str(tmp_path / "e.taxid"))
+    assert (tmp_path / "e.vw").read_bytes() == b"" and (tmp_path / "e.taxid").read_bytes() == b""
