@@ -170,7 +170,7 @@ def main():
 
         def step():
             check(lib().opal_features(eng._h, batch.data.data_ptr(), batch.nbytes, batch.off.data_ptr(), batch.len.data_ptr(),
-                                      batch.n, 1, bits, offsets.data_ptr(), out_idx.data_ptr()), eng._h)
+                                      batch.n, 1, bits, offsets.data_ptr(), out_idx.data_ptr(), total), eng._h)
     else:
         def step():
             eng.predict(batch, True, want_scores=False, out_class=out_class)

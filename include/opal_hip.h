@@ -107,17 +107,20 @@ int opal_feature_offsets(opal_ctx *ctx, const uint32_t *d_frag_len, uint64_t n, 
  * (util/fasta2skm.py:137-141,78-80; vw parse of the line written at opal.py:366-367,468-469):
  * d_out_idx[d_out_off[i] + f] = hash(name of feature f of fragment i) & (2^bits - 1), features in the
  * reference's order (forward strand window-major / pattern-minor, then the reverse complement).
- * d_out_off must have been filled by opal_feature_offsets with the same `reverse`.                          */
+ * d_out_off must have been filled by opal_feature_offsets with the same `reverse`.  out_cap = number of
+ * indices d_out_idx can hold (normally d_out_off[n]); a fragment whose range would pass it is not written,
+ * so offsets that belong to another batch cannot make the kernel write outside the buffer.                  */
 int opal_features(opal_ctx *ctx, const uint8_t *d_reads, uint64_t reads_bytes, const uint64_t *d_frag_off,
                   const uint32_t *d_frag_len, uint64_t n, int reverse, int bits, const uint64_t *d_out_off,
-                  uint32_t *d_out_idx);
+                  uint32_t *d_out_idx, uint64_t out_cap);
 
 /* Debug twin of opal_features: writes the t gathered characters of every feature (the feature NAME without
  * its decimal pattern suffix) so that the host can rebuild the reference's VW text line byte for byte
- * (util/fasta2skm.py:81-82).  d_out_names holds t bytes per feature at (d_out_off[i]+f)*t.                  */
+ * (util/fasta2skm.py:81-82).  d_out_names holds t bytes per feature at (d_out_off[i]+f)*t; out_cap = number
+ * of FEATURES it can hold (t bytes each), checked like opal_features' out_cap.                                */
 int opal_feature_names(opal_ctx *ctx, const uint8_t *d_reads, uint64_t reads_bytes, const uint64_t *d_frag_off,
                        const uint32_t *d_frag_len, uint64_t n, int reverse, const uint64_t *d_out_off,
-                       uint8_t *d_out_names);
+                       uint8_t *d_out_names, uint64_t out_cap);
 
 /* Fused predict. Replaces fasta2skm.main_generator piped into `vw -t -i model -p preds` (opal.py:449-469):
  * d_out_class[i] = 1-based VW class of fragment i (what vw writes to the -p file), d_out_scores (optional,

@@ -25,9 +25,16 @@
 
 namespace {
 
+// F_j of opal_feature_offsets for one fragment (length word with the raw flag)
+__device__ __forceinline__ uint64_t feature_count(uint32_t len_word, const Geom &G)
+{
+    const uint32_t len = len_word & ~OPAL_RAW_FLAG;
+    return len >= (uint32_t)G.k ? (uint64_t)(len - (uint32_t)G.k + 1u) * (uint64_t)G.P * (G.reverse ? 2u : 1u) : 0ull;
+}
+
 // ------------------------------------------------------------------------------------------ emit kernels
 __global__ __launch_bounds__(BLOCK) void emit_idx_kernel(Batch B, Geom G, uint32_t mask, const uint64_t *__restrict__ out_off,
-                                                          uint32_t *__restrict__ out_idx)
+                                                          uint32_t *__restrict__ out_idx, uint64_t out_cap)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_seq[WPB][2 * SEQB];
     __shared__ __attribute__((aligned(16))) uint32_t s_hb[WPB][HB + HB_PAD];
@@ -37,7 +44,9 @@ __global__ __launch_bounds__(BLOCK) void emit_idx_kernel(Batch B, Geom G, uint32
     fill_kmer4_table(s_tab);
     const uint64_t nwaves = (uint64_t)gridDim.x * WPB;
     for (uint64_t frag = (uint64_t)blockIdx.x * WPB + wv; frag < B.n; frag += nwaves) {
-        uint32_t *dst = out_idx + out_off[frag];
+        const uint64_t o0 = out_off[frag];
+        if (o0 > out_cap || feature_count(B.len[frag], G) > out_cap - o0) continue;   // never write outside out_idx
+        uint32_t *dst = out_idx + o0;
         uint32_t *hb = s_hb[wv];
         walk_fragment(B, G, frag, mask, false, 0u, s_seq[wv], hb, s_tab, lane, [&](uint32_t cnt) {
             if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {   // wave-uniform: 16-byte stores, then the tail
@@ -57,7 +66,7 @@ __global__ __launch_bounds__(BLOCK) void emit_idx_kernel(Batch B, Geom G, uint32
 
 // Debug: the t gathered characters of every feature (reference order), t bytes per feature.
 __global__ __launch_bounds__(BLOCK) void emit_names_kernel(Batch B, Geom G, const uint64_t *__restrict__ out_off,
-                                                            uint8_t *__restrict__ out_names)
+                                                            uint8_t *__restrict__ out_names, uint64_t out_cap)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_seq[WPB][SEQB];
     const int lane = threadIdx.x & (WAVE - 1);
@@ -74,6 +83,7 @@ __global__ __launch_bounds__(BLOCK) void emit_names_kernel(Batch B, Geom G, cons
         const uint32_t W = len - (uint32_t)k + 1u;
         const uint32_t tw_seq = (uint32_t)(SEQB - k + 1);
         uint64_t f0 = out_off[frag];
+        if (f0 > out_cap || feature_count(B.len[frag], G) > out_cap - f0) continue;   // never write outside out_names
         for (int s = 0; s < (G.reverse ? 2 : 1); s++) {
             for (uint32_t w0 = 0; w0 < W; w0 += tw_seq) {
                 const uint32_t tw = min(W - w0, tw_seq);
@@ -476,7 +486,7 @@ extern "C" int opal_feature_offsets(opal_ctx *ctx, const uint32_t *d_frag_len, u
 
 extern "C" int opal_features(opal_ctx *ctx, const uint8_t *d_reads, uint64_t reads_bytes, const uint64_t *d_frag_off,
                              const uint32_t *d_frag_len, uint64_t n, int reverse, int bits, const uint64_t *d_out_off,
-                             uint32_t *d_out_idx)
+                             uint32_t *d_out_idx, uint64_t out_cap)
 {
     int rc = check_batch(ctx, "opal_features", d_reads, d_frag_off, d_frag_len, n);
     if (rc) return rc;
@@ -490,14 +500,14 @@ extern "C" int opal_features(opal_ctx *ctx, const uint8_t *d_reads, uint64_t rea
     int grid = 1;
     rc = grid_for(ctx, (const void *)&emit_idx_kernel, n, &grid);
     if (rc) return rc;
-    hipLaunchKernelGGL(emit_idx_kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, B, G, mask, d_out_off, d_out_idx);
+    hipLaunchKernelGGL(emit_idx_kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, B, G, mask, d_out_off, d_out_idx, out_cap);
     OPAL_HIP_CHECK(ctx, hipGetLastError());
     return OPAL_OK;
 }
 
 extern "C" int opal_feature_names(opal_ctx *ctx, const uint8_t *d_reads, uint64_t reads_bytes, const uint64_t *d_frag_off,
                                   const uint32_t *d_frag_len, uint64_t n, int reverse, const uint64_t *d_out_off,
-                                  uint8_t *d_out_names)
+                                  uint8_t *d_out_names, uint64_t out_cap)
 {
     int rc = check_batch(ctx, "opal_feature_names", d_reads, d_frag_off, d_frag_len, n);
     if (rc) return rc;
@@ -509,7 +519,7 @@ extern "C" int opal_feature_names(opal_ctx *ctx, const uint8_t *d_reads, uint64_
     int grid = 1;
     rc = grid_for(ctx, (const void *)&emit_names_kernel, n, &grid);
     if (rc) return rc;
-    hipLaunchKernelGGL(emit_names_kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, B, G, d_out_off, d_out_names);
+    hipLaunchKernelGGL(emit_names_kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, B, G, d_out_off, d_out_names, out_cap);
     OPAL_HIP_CHECK(ctx, hipGetLastError());
     return OPAL_OK;
 }

@@ -227,7 +227,7 @@ class Engine:
         total = int(offsets[-1].item())
         idx = t.empty(max(total, 1), dtype=t.int32, device=self.device)
         check(lib().opal_features(self._h, b.data.data_ptr(), b.nbytes, b.off.data_ptr(), b.len.data_ptr(), b.n,
-                                  int(reverse), bits, offsets.data_ptr(), idx.data_ptr()), self._h)
+                                  int(reverse), bits, offsets.data_ptr(), idx.data_ptr(), total), self._h)
         return idx[:total], offsets
 
     def feature_names(self, b: DeviceBatch, reverse: bool, offsets=None):
@@ -237,7 +237,7 @@ class Engine:
         total = int(offsets[-1].item())
         names = t.empty(max(total * self.t, 1), dtype=t.uint8, device=self.device)
         check(lib().opal_feature_names(self._h, b.data.data_ptr(), b.nbytes, b.off.data_ptr(), b.len.data_ptr(), b.n,
-                                       int(reverse), offsets.data_ptr(), names.data_ptr()), self._h)
+                                       int(reverse), offsets.data_ptr(), names.data_ptr(), total), self._h)
         return names[:total * self.t].view(total, self.t) if total else names[:0].view(0, self.t), offsets
 
     def predict(self, b: DeviceBatch, reverse: bool, want_scores=False, out_class=None, out_scores=None):

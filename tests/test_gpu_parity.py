@@ -430,6 +430,34 @@ def test_run_patterns_and_unsorted_rows_against_oracle(amd, eng, oracle):
             assert np.array_equal(_u32(idx), oidx), (k, pos[0, 0], reverse)
 
 
+def test_emit_never_writes_past_out_cap(amd, eng, oracle, golden_dir):
+    """out_cap of opal_features / opal_feature_names: fragments whose range passes it are skipped, everything
+    before is written as usual, nothing lands beyond the capacity."""
+    import torch
+    from opal_amd._lib import check, lib
+    with open(os.path.join(golden_dir, "patterns_k64_t16_m1_s7.txt")) as f:
+        pos = amd.parse_patterns(f.readlines(), 64)
+    eng.set_patterns(pos, 64)
+    rng = np.random.default_rng(11)
+    seqs = _rand_seqs(rng, 40, 200)
+    b = eng.upload(amd.PackedReads.from_sequences(seqs))
+    off = eng.feature_offsets(b, True)
+    total = int(off[-1].item())
+    oidx, _ = oracle.features_batch(seqs, 64, pos, True, 31)
+    cut = int(off[25].item()) + 7                              # capacity ends inside fragment 25
+    idx = torch.full((total,), -1, dtype=torch.int32, device=eng.device)
+    check(lib().opal_features(eng._h, b.data.data_ptr(), b.nbytes, b.off.data_ptr(), b.len.data_ptr(), b.n, 1, 31,
+                              off.data_ptr(), idx.data_ptr(), cut), eng._h)
+    got = _u32(idx)
+    keep = int(off[25].item())
+    assert np.array_equal(got[:keep], oidx[:keep])
+    assert np.all(got[keep:] == 0xffffffff)
+    names = torch.full((total * 16,), 7, dtype=torch.uint8, device=eng.device)
+    check(lib().opal_feature_names(eng._h, b.data.data_ptr(), b.nbytes, b.off.data_ptr(), b.len.data_ptr(), b.n, 1,
+                                   off.data_ptr(), names.data_ptr(), cut), eng._h)
+    assert bool((names[keep * 16:] == 7).all()) and not bool((names[:keep * 16] == 7).any())
+
+
 def test_randomised_predict_switches_against_oracle(amd, eng, oracle):
     rng = np.random.default_rng(77001)
     for trial in range(40):
