@@ -232,14 +232,14 @@ def main():
         import shutil
         res["vw_binary_on_box"] = shutil.which("vw")       # time a real vw if one exists (never seen so far)
         if world == 1 and not args.no_cpu_baseline and codes is not None:
-            res["cpu_baseline"] = cpu_baseline(codes, pos, k, w, K, bits, mode, min(args.cpu_sample, n), out_class, eng, batch)
+            res["cpu_baseline"] = cpu_baseline(codes, pos, k, w, K, bits, mode, min(args.cpu_sample, n), out_class)
         print(json.dumps(res), flush=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(codes, pos, k, w, K, bits, mode, m, out_class, eng, batch):
+def cpu_baseline(codes, pos, k, w, K, bits, mode, m, out_class):
     """Times the CPU oracle (the checker, a scalar C port with OpenMP over fragments) on the first m fragments."""
     from oracle import oracle as orc
     orc.build()

@@ -13,8 +13,6 @@ import itertools
 import os
 import sys
 
-import numpy as np
-
 from .engine import Engine, PackedReads, parse_patterns
 from .fasta_functions import fasta_reader
 

@@ -278,7 +278,7 @@ def train(ref_dir, model_dir, args, engine=None):
 
 
 # ------------------------------------------------------------------ predict (reference opal.py:392-493)
-def predict(model_dir, test_dir, predict_dir, args, engine=None, chunk=2_000_000):
+def predict(model_dir, test_dir, predict_dir, args, engine=None):
     kmer, reverse = args.kmer, args.reverse_complement
     try:
         fasta = glob.glob(test_dir + "/*.fasta")[0]

@@ -3,7 +3,6 @@
 import os, sys, time, tempfile
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import opal_amd
 from opal_amd import opal, model as model_io
 
 n, L, K, bits = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000, 200, 356, 31
@@ -23,7 +22,6 @@ with open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "patt
 open(d + "/model/vw-dico.txt", "w").write("".join("tax%d\t%d\n" % (i, i) for i in range(1, K + 1)))
 idx = rng.integers(0, 1 << bits, size=5_000_000).astype(np.uint32)
 val = (rng.standard_normal(idx.size) * 0.05).astype(np.float32)
-import struct
 with open(d + "/model/vw-model_final.model", "wb") as f:
     f.write(model_io._HDR.pack(model_io.MAGIC, 1, bits, K, 6, -1.0, 1.0, idx.size, 0, 0)); idx.tofile(f); val.tofile(f)
 print("setup %.1fs, fasta %.0f MB" % (time.time() - t0, os.path.getsize(d + "/test/reads.fasta") / 1e6), flush=True)

@@ -6,7 +6,6 @@ import json
 import os
 
 import numpy as np
-import pytest
 
 
 def _load(golden_dir, name):
