@@ -9,7 +9,8 @@
 // Everything is a prefix scan over bytes with a small associative state:
 //   state(i) = (# header lines started at or before i, last '>'/'+' event, type of the line byte i belongs to)
 //   content(i) = byte i is sequence text  ->  its output position is the exclusive sum of content flags,
-// then one wave per record classifies it (all upper-case ACGT -> 2-bit packed, else raw) and writes it out.
+// then records are classified (all upper-case ACGT -> 2-bit packed, else raw) by a flat pass over the sequence bytes
+// and written out: one wave per short record, the whole grid per long record (genomes).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -107,6 +108,19 @@ __device__ __forceinline__ uint64_t block_excl_scan_u64(uint64_t v, uint64_t *s_
     return base + incl - v;
 }
 
+// the ING_ITEMS bytes of one thread: one 16-byte load when the text pointer allows it (bytes past the end read as '\n')
+__device__ __forceinline__ void load_items(const uint8_t *__restrict__ text, uint64_t n, uint64_t base, uint8_t (&c)[ING_ITEMS])
+{
+    static_assert(ING_ITEMS == 16, "one uint4 per thread");
+    if (base + ING_ITEMS <= n && (reinterpret_cast<uintptr_t>(text) & 15u) == 0) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(text + base);
+        __builtin_memcpy(c, &v, ING_ITEMS);
+    } else {
+#pragma unroll
+        for (int i = 0; i < ING_ITEMS; i++) c[i] = base + i < n ? text[base + i] : (uint8_t)'\n';
+    }
+}
+
 // pass 1: per-tile aggregate state
 __global__ __launch_bounds__(BLOCK) void ing_tile_state_kernel(const uint8_t *__restrict__ text, uint64_t n, St *__restrict__ tile_st)
 {
@@ -114,13 +128,14 @@ __global__ __launch_bounds__(BLOCK) void ing_tile_state_kernel(const uint8_t *__
     const uint64_t base = (uint64_t)blockIdx.x * ING_TILE + (uint64_t)threadIdx.x * ING_ITEMS;
     St agg{0, 0, 0};
     uint32_t prev = (base > 0 && base <= n) ? text[base - 1] : 0;
+    uint8_t c[ING_ITEMS];
+    load_items(text, n, base, c);
 #pragma unroll
     for (int i = 0; i < ING_ITEMS; i++) {
         const uint64_t p = base + i;
         if (p < n) {
-            const uint32_t c = text[p];
-            agg = st_combine(agg, st_of_byte(c, prev, p == 0));
-            prev = c;
+            agg = st_combine(agg, st_of_byte(c[i], prev, p == 0));
+            prev = c[i];
         }
     }
     St total;
@@ -128,20 +143,32 @@ __global__ __launch_bounds__(BLOCK) void ing_tile_state_kernel(const uint8_t *__
     if (threadIdx.x == 0) tile_st[blockIdx.x] = total;
 }
 
-// pass 2: exclusive scan of the tile aggregates by one block; grand total to *total_out
+// pass 2: exclusive scan of the tile aggregates by one block (SC_ITEMS consecutive tiles per thread and round);
+// grand total to *total_out
+constexpr int SC_ITEMS = 8;
 __global__ __launch_bounds__(BLOCK) void ing_scan_tiles_st_kernel(St *__restrict__ tile_st, uint64_t ntiles, St *__restrict__ total_out)
 {
     __shared__ St s_w[WPB];
     __shared__ St s_carry;
     if (threadIdx.x == 0) s_carry = St{0, 0, 0};
     __syncthreads();
-    for (uint64_t b0 = 0; b0 < ntiles; b0 += BLOCK) {
-        const uint64_t i = b0 + threadIdx.x;
-        const St v = i < ntiles ? tile_st[i] : St{0, 0, 0};
+    for (uint64_t b0 = 0; b0 < ntiles; b0 += (uint64_t)BLOCK * SC_ITEMS) {
+        const uint64_t i0 = b0 + (uint64_t)threadIdx.x * SC_ITEMS;
+        St v[SC_ITEMS], agg{0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < SC_ITEMS; j++) {
+            v[j] = i0 + j < ntiles ? tile_st[i0 + j] : St{0, 0, 0};
+            agg = st_combine(agg, v[j]);
+        }
         St total;
-        const St excl = block_excl_scan_st(v, s_w, total);
+        const St excl = block_excl_scan_st(agg, s_w, total);
         const St carry = s_carry;
-        if (i < ntiles) tile_st[i] = st_combine(carry, excl);
+        St run = st_combine(carry, excl);
+#pragma unroll
+        for (int j = 0; j < SC_ITEMS; j++) {
+            if (i0 + j < ntiles) tile_st[i0 + j] = run;
+            run = st_combine(run, v[j]);
+        }
         __syncthreads();
         if (threadIdx.x == 0) s_carry = st_combine(carry, total);
         __syncthreads();
@@ -155,13 +182,23 @@ __global__ __launch_bounds__(BLOCK) void ing_scan_tiles_u64_kernel(uint64_t *__r
     __shared__ uint64_t s_carry;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
-    for (uint64_t b0 = 0; b0 < ntiles; b0 += BLOCK) {
-        const uint64_t i = b0 + threadIdx.x;
-        const uint64_t v = i < ntiles ? tile_v[i] : 0ull;
+    for (uint64_t b0 = 0; b0 < ntiles; b0 += (uint64_t)BLOCK * SC_ITEMS) {
+        const uint64_t i0 = b0 + (uint64_t)threadIdx.x * SC_ITEMS;
+        uint64_t v[SC_ITEMS], agg = 0;
+#pragma unroll
+        for (int j = 0; j < SC_ITEMS; j++) {
+            v[j] = i0 + j < ntiles ? tile_v[i0 + j] : 0ull;
+            agg += v[j];
+        }
         uint64_t total;
-        const uint64_t excl = block_excl_scan_u64(v, s_w, total);
+        const uint64_t excl = block_excl_scan_u64(agg, s_w, total);
         const uint64_t carry = s_carry;
-        if (i < ntiles) tile_v[i] = carry + excl;
+        uint64_t run = carry + excl;
+#pragma unroll
+        for (int j = 0; j < SC_ITEMS; j++) {
+            if (i0 + j < ntiles) tile_v[i0 + j] = run;
+            run += v[j];
+        }
         __syncthreads();
         if (threadIdx.x == 0) s_carry = carry + total;
         __syncthreads();
@@ -185,10 +222,10 @@ __global__ __launch_bounds__(BLOCK) void ing_content_kernel(const uint8_t *__res
     St agg{0, 0, 0};
     uint32_t prev0 = (base > 0 && base <= n) ? text[base - 1] : 0;
     uint32_t prev = prev0;
+    load_items(text, n, base, c);
 #pragma unroll
     for (int i = 0; i < ING_ITEMS; i++) {
         const uint64_t p = base + i;
-        c[i] = p < n ? text[p] : (uint8_t)'\n';
         if (p < n) {
             agg = st_combine(agg, st_of_byte(c[i], prev, p == 0));
             prev = c[i];
@@ -232,29 +269,68 @@ __global__ __launch_bounds__(BLOCK) void ing_content_kernel(const uint8_t *__res
     }
 }
 
-// one wave per record: length, ACGT-only?, output bytes
-__global__ __launch_bounds__(BLOCK) void ing_classify_kernel(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ seq_start,
-                                                              uint64_t n_rec, uint64_t total_content,
-                                                              uint32_t *__restrict__ frag_len, uint64_t *__restrict__ rec_bytes,
-                                                              uint64_t *__restrict__ too_long)
+// Classification is flat over the compacted sequence bytes, so one 4 Mbp genome occupies the whole chip just as
+// 4M short reads do: a thread looks at 16 bytes; only a byte outside ACGT (rare) costs a binary search for its
+// record and a store of 1 into that record's flag.
+constexpr int CL_ITEMS = 16;
+__device__ __forceinline__ uint64_t record_of(const uint64_t *__restrict__ seq_start, uint64_t n_rec, uint64_t pos)
 {
-    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
-    const uint64_t nwaves = (uint64_t)gridDim.x * WPB;
-    for (uint64_t r = (uint64_t)blockIdx.x * WPB + wv; r < n_rec; r += nwaves) {
+    // last r with seq_start[r] <= pos (empty records share a start with their successor: the last one holds the byte)
+    uint64_t lo = 0, hi = n_rec - 1;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi + 1) >> 1;
+        if (seq_start[mid] <= pos) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(BLOCK) void ing_classify_kernel(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ seq_start,
+                                                              uint64_t n_rec, uint64_t total_content, uint32_t *__restrict__ raw_flag)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * BLOCK * CL_ITEMS;
+    for (uint64_t base = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * CL_ITEMS; base < total_content; base += stride) {
+        uint8_t c[CL_ITEMS];
+        if (base + CL_ITEMS <= total_content) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(seq + base);      // seq comes from hipMalloc, base % 16 == 0
+            __builtin_memcpy(c, &v, CL_ITEMS);
+        } else {
+#pragma unroll
+            for (int i = 0; i < CL_ITEMS; i++) c[i] = base + i < total_content ? seq[base + i] : (uint8_t)'A';
+        }
+        uint32_t bad = 0;
+#pragma unroll
+        for (int i = 0; i < CL_ITEMS; i++) {
+            const uint32_t ch = c[i];
+            if (!(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T')) bad |= 1u << i;
+        }
+        while (bad) {
+            const int i = __builtin_ctz(bad);
+            bad &= bad - 1;
+            raw_flag[record_of(seq_start, n_rec, base + i)] = 1u;   // same value from every writer
+        }
+    }
+}
+
+// per record: length word, output bytes; records longer than LONG_BASES go on the list of ing_pack_long_kernel
+constexpr uint64_t LONG_BASES = 1u << 16;
+constexpr uint32_t LONG_CAP = 1u << 16;
+__global__ __launch_bounds__(BLOCK) void ing_lens_kernel(const uint64_t *__restrict__ seq_start, uint64_t n_rec, uint64_t total_content,
+                                                          const uint32_t *__restrict__ raw_flag, uint32_t *__restrict__ frag_len,
+                                                          uint64_t *__restrict__ rec_bytes, uint64_t *__restrict__ too_long,
+                                                          unsigned int *__restrict__ long_count, uint64_t *__restrict__ long_list)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t r = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; r < n_rec; r += stride) {
         const uint64_t s = seq_start[r];
         const uint64_t e = (r + 1 < n_rec) ? seq_start[r + 1] : total_content;
         const uint64_t len = e - s;
-        bool ok = true;
-        for (uint64_t i = s + lane; i < e; i += WAVE) {
-            const uint32_t ch = seq[i];
-            ok = ok && (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T');
-        }
-        const bool acgt = __all(ok);
-        if (lane == 0) {
-            if (len > 0x7fffffffull) *too_long = 1;       // reported as OPAL_EINVAL by the host; plain store of a constant
-            const uint32_t l31 = len > 0x7fffffffull ? 0x7fffffffu : (uint32_t)len;
-            frag_len[r] = l31 | (acgt ? 0u : OPAL_RAW_FLAG);
-            rec_bytes[r] = acgt ? (len + 3) / 4 : len;
+        const bool raw = raw_flag[r] != 0;
+        if (len > 0x7fffffffull) *too_long = 1;           // reported as OPAL_EINVAL by the host; plain store of a constant
+        const uint32_t l31 = len > 0x7fffffffull ? 0x7fffffffu : (uint32_t)len;
+        frag_len[r] = l31 | (raw ? OPAL_RAW_FLAG : 0u);
+        rec_bytes[r] = raw ? len : (len + 3) / 4;
+        if (len > LONG_BASES) {
+            const unsigned int at = atomicAdd(long_count, 1u);
+            if (at < LONG_CAP) long_list[at] = r;
         }
     }
 }
@@ -293,39 +369,67 @@ __global__ __launch_bounds__(BLOCK) void ing_rec_scan_kernel(const uint64_t *__r
     }
 }
 
-// one wave per record: write the packed (4 bases/byte) or raw copy
+// output bytes [b0, b1) of one record, strided over by `nthreads` threads of which this is number `tid`
+__device__ __forceinline__ void pack_span(const uint8_t *__restrict__ seq, uint64_t s, uint64_t len, bool raw, uint8_t *__restrict__ dst,
+                                          uint64_t b0, uint64_t b1, uint64_t tid, uint64_t nthreads)
+{
+    if (raw) {
+        for (uint64_t i = b0 + tid; i < b1; i += nthreads) dst[i] = seq[s + i];
+        return;
+    }
+    // 4 letters per output byte: two aligned dwords + v_alignbyte instead of four byte loads (seq has 16 bytes of
+    // slack behind its last byte), then all four codes at once
+    const uint32_t *__restrict__ seq4 = reinterpret_cast<const uint32_t *>(seq);
+    for (uint64_t b = b0 + tid; b < b1; b += nthreads) {
+        const uint64_t a = s + 4 * b;
+        const uint32_t x = __builtin_amdgcn_alignbyte(seq4[(a >> 2) + 1], seq4[a >> 2], (uint32_t)(a & 3));
+        // A=0x41 C=0x43 G=0x47 T=0x54: (ch >> 1) & 3 gives 0,1,3,2 -> fix the G/T order
+        uint32_t q = (x >> 1) & 0x03030303u;
+        q ^= (q >> 1) & 0x01010101u;
+        const uint64_t left = len - 4 * b;                                    // letters of the record from here on (>= 1)
+        if (left < 4) q &= (1u << (8 * (uint32_t)left)) - 1u;
+        dst[b] = (uint8_t)((q | (q >> 6) | (q >> 12) | (q >> 18)) & 0xffu);
+    }
+}
+
+// one wave per record: write the packed (4 bases/byte) or raw copy.  Records on the long list are left to
+// ing_pack_long_kernel (unless the list overflowed: then every record is handled here).
 __global__ __launch_bounds__(BLOCK) void ing_pack_kernel(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ seq_start,
                                                           const uint32_t *__restrict__ frag_len, const uint64_t *__restrict__ out_byte_off,
-                                                          uint64_t n_rec, uint8_t *__restrict__ out, uint64_t out_cap)
+                                                          uint64_t n_rec, uint8_t *__restrict__ out, uint64_t out_cap,
+                                                          const unsigned int *__restrict__ long_count)
 {
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
     const uint64_t nwaves = (uint64_t)gridDim.x * WPB;
+    const bool split_long = *long_count <= LONG_CAP;
     for (uint64_t r = (uint64_t)blockIdx.x * WPB + wv; r < n_rec; r += nwaves) {
-        const uint64_t s = seq_start[r];
         const uint32_t lw = frag_len[r];
         const uint64_t len = lw & ~OPAL_RAW_FLAG;
-        const uint64_t o = out_byte_off[r];
-        if (lw & OPAL_RAW_FLAG) {
-            if (o + len > out_cap) continue;
-            for (uint64_t i = lane; i < len; i += WAVE) out[o + i] = seq[s + i];
-        } else {
-            const uint64_t nb = (len + 3) / 4;
-            if (o + nb > out_cap) continue;
-            for (uint64_t b = lane; b < nb; b += WAVE) {
-                uint32_t v = 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint64_t p = 4 * b + j;
-                    if (p < len) {
-                        const uint32_t ch = seq[s + p];
-                        // A=0x41 C=0x43 G=0x47 T=0x54: (ch >> 1) & 3 gives 0,1,3,2 -> fix G/T order
-                        const uint32_t q = (ch >> 1) & 3u;
-                        v |= (q ^ (q >> 1)) << (2 * j);
-                    }
-                }
-                out[o + b] = (uint8_t)v;
-            }
-        }
+        if (split_long && len > LONG_BASES) continue;
+        const bool raw = (lw & OPAL_RAW_FLAG) != 0;
+        const uint64_t o = out_byte_off[r], nb = raw ? len : (len + 3) / 4;
+        if (o + nb > out_cap) continue;
+        pack_span(seq, seq_start[r], len, raw, out + o, 0, nb, (uint64_t)lane, WAVE);
+    }
+}
+
+// the long records (genomes), one after the other, each spread over the whole grid
+__global__ __launch_bounds__(BLOCK) void ing_pack_long_kernel(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ seq_start,
+                                                               const uint32_t *__restrict__ frag_len, const uint64_t *__restrict__ out_byte_off,
+                                                               uint8_t *__restrict__ out, uint64_t out_cap,
+                                                               const unsigned int *__restrict__ long_count, const uint64_t *__restrict__ long_list)
+{
+    const unsigned int n_long = *long_count;
+    if (n_long > LONG_CAP) return;
+    const uint64_t tid = (uint64_t)blockIdx.x * BLOCK + threadIdx.x, nthreads = (uint64_t)gridDim.x * BLOCK;
+    for (unsigned int li = 0; li < n_long; li++) {
+        const uint64_t r = long_list[li];
+        const uint32_t lw = frag_len[r];
+        const uint64_t len = lw & ~OPAL_RAW_FLAG;
+        const bool raw = (lw & OPAL_RAW_FLAG) != 0;
+        const uint64_t o = out_byte_off[r], nb = raw ? len : (len + 3) / 4;
+        if (o + nb > out_cap) continue;
+        pack_span(seq, seq_start[r], len, raw, out + o, 0, nb, tid, nthreads);
     }
 }
 
@@ -358,10 +462,11 @@ extern "C" int opal_ingest_fasta(opal_ctx *ctx, const uint8_t *d_text, uint64_t 
     // scratch: [tile states | tile counts | totals] , compacted text, record starts, record bytes/offsets
     int rc = grow(ctx, &ctx->ing_tiles, &ctx->ing_tiles_cap, ntiles * (sizeof(St) + sizeof(uint64_t)) + 256);
     if (rc) return rc;
-    rc = grow(ctx, &ctx->ing_seq, &ctx->ing_seq_cap, nbytes);
+    rc = grow(ctx, &ctx->ing_seq, &ctx->ing_seq_cap, nbytes + 16);   // slack: the packer reads whole dwords
     if (rc) return rc;
     const uint64_t rec_tiles = (max_records + RS_TILE - 1) / RS_TILE;
-    rc = grow(ctx, &ctx->ing_rec, &ctx->ing_rec_cap, (max_records + 1) * 3 * sizeof(uint64_t) + rec_tiles * sizeof(uint64_t) + 256);
+    rc = grow(ctx, &ctx->ing_rec, &ctx->ing_rec_cap, (max_records + 1) * (3 * sizeof(uint64_t) + sizeof(uint32_t)) +
+                                                       (rec_tiles + LONG_CAP) * sizeof(uint64_t) + 256);
     if (rc) return rc;
     St *tile_st = (St *)ctx->ing_tiles;
     uint64_t *tile_cnt = (uint64_t *)(tile_st + ntiles);
@@ -374,6 +479,9 @@ extern "C" int opal_ingest_fasta(opal_ctx *ctx, const uint8_t *d_text, uint64_t 
     uint64_t *rec_bytes = seq_start + (max_records + 1);
     uint64_t *out_byte_off = rec_bytes + (max_records + 1);
     uint64_t *rec_tile_v = out_byte_off + (max_records + 1);
+    uint64_t *long_list = rec_tile_v + rec_tiles;
+    unsigned int *long_count = (unsigned int *)(long_list + LONG_CAP);      // 2 x u32 (8-byte slot)
+    uint32_t *raw_flag = (uint32_t *)(long_count + 2);
 
     hipLaunchKernelGGL(ing_tile_state_kernel, dim3((unsigned)ntiles), dim3(BLOCK), 0, st, d_text, nbytes, tile_st);
     hipLaunchKernelGGL(ing_scan_tiles_st_kernel, dim3(1), dim3(BLOCK), 0, st, tile_st, ntiles, total_st);
@@ -402,7 +510,11 @@ extern "C" int opal_ingest_fasta(opal_ctx *ctx, const uint8_t *d_text, uint64_t 
     if (n_rec == 0) return OPAL_OK;
     const int wgrid = (int)std::max<uint64_t>(1, std::min<uint64_t>((n_rec + WPB - 1) / WPB, (uint64_t)ctx->num_cus * 8));
     OPAL_HIP_CHECK(ctx, hipMemsetAsync(too_long, 0, sizeof(uint64_t), st));
-    hipLaunchKernelGGL(ing_classify_kernel, dim3(wgrid), dim3(BLOCK), 0, st, seq, seq_start, n_rec, T, d_frag_len, rec_bytes, too_long);
+    OPAL_HIP_CHECK(ctx, hipMemsetAsync(long_count, 0, 2 * sizeof(unsigned int) + n_rec * sizeof(uint32_t), st));   // count + flags
+    const int fgrid = ctx->num_cus * 8;
+    if (T) hipLaunchKernelGGL(ing_classify_kernel, dim3(fgrid), dim3(BLOCK), 0, st, seq, seq_start, n_rec, T, raw_flag);
+    hipLaunchKernelGGL(ing_lens_kernel, dim3((unsigned)std::min<uint64_t>((n_rec + BLOCK - 1) / BLOCK, (uint64_t)fgrid)), dim3(BLOCK), 0, st,
+                       seq_start, n_rec, T, raw_flag, d_frag_len, rec_bytes, too_long, long_count, long_list);
     const uint64_t rt = (n_rec + RS_TILE - 1) / RS_TILE;
     hipLaunchKernelGGL(ing_rec_scan_kernel<false>, dim3((unsigned)rt), dim3(BLOCK), 0, st, rec_bytes, d_frag_len, n_rec, rec_tile_v, out_byte_off, d_frag_off);
     hipLaunchKernelGGL(ing_scan_tiles_u64_kernel, dim3(1), dim3(BLOCK), 0, st, rec_tile_v, rt, total_out);
@@ -414,7 +526,10 @@ extern "C" int opal_ingest_fasta(opal_ctx *ctx, const uint8_t *d_text, uint64_t 
     const uint64_t out_bytes = tail[0];
     if (tail[1]) return opal::fail(ctx, OPAL_EINVAL, "opal_ingest_fasta: a record is longer than 2^31-1 bases");
     if (out_bytes > reads_cap) return opal::fail(ctx, OPAL_ERANGE, "opal_ingest_fasta: d_reads_out too small");
-    hipLaunchKernelGGL(ing_pack_kernel, dim3(wgrid), dim3(BLOCK), 0, st, seq, seq_start, d_frag_len, out_byte_off, n_rec, d_reads_out, reads_cap);
+    hipLaunchKernelGGL(ing_pack_kernel, dim3(wgrid), dim3(BLOCK), 0, st, seq, seq_start, d_frag_len, out_byte_off, n_rec, d_reads_out, reads_cap,
+                       long_count);
+    hipLaunchKernelGGL(ing_pack_long_kernel, dim3(fgrid), dim3(BLOCK), 0, st, seq, seq_start, d_frag_len, out_byte_off, d_reads_out, reads_cap,
+                       long_count, long_list);
     OPAL_HIP_CHECK(ctx, hipGetLastError());
     *reads_bytes_out = out_bytes;
     return OPAL_OK;

@@ -302,6 +302,16 @@ def test_gpu_fasta_ingest_matches_reference_reader(amd, eng, oracle, golden_dir)
     big = b"junk before the first header\n" + b"".join(parts)
     assert len(big) > 200 * 4096
     _check_ingest(amd, eng, oracle, big)
+    # genome-sized records (the grid-wide path of the packer: > 65 536 bases), packed and raw, between short ones
+    def wrapped(body, width=70):
+        return b"\n".join(body[j:j + width] for j in range(0, len(body), width)) + b"\n"
+    g1 = bytes(rng.choice(ACGT, size=300_001))
+    g2 = bytearray(rng.choice(ACGT, size=70_000))
+    g2[65_999] = ord("N")
+    g3 = bytes(rng.choice(ACGT, size=65_537))
+    genomes = (b">short1\nACGTACGT\n>g1 packed genome\n" + wrapped(g1) + b">empty\n>g2 raw genome\n" + wrapped(bytes(g2), 61) +
+               b">short2\nacgtn\n>g3\n" + wrapped(g3, 80) + b">edge\n" + wrapped(bytes(rng.choice(ACGT, size=65_536))))
+    _check_ingest(amd, eng, oracle, genomes)
     # end to end: predictions from the ingested batch equal predictions from host-parsed records
     pos = _patterns(amd, golden_dir, "patterns_k64_t16_m1_s7.txt", 64)
     eng.set_patterns(pos, 64)
