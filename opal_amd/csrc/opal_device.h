@@ -193,6 +193,28 @@ __device__ __forceinline__ uint32_t hash_name_tab(const uint8_t *wb, const uint3
     return mm_fin(h, T + 1);
 }
 
+// Raw (text) fragments with t = 16: murmur over the gathered letters in registers, as hash_name_generic computes
+// it, plus a 4-bytes-at-a-time test whether the name is all digits (the `--hash strings` rule then applies and the
+// caller falls back to hash_name_generic; it never happens for DNA text).
+template <int T>
+__device__ __forceinline__ uint32_t hash_name_ascii(const uint8_t *wb, const uint32_t (&pq)[T / 4], int p, bool &all_digits)
+{
+    uint32_t h = 0;
+    bool dig = true;
+#pragma unroll
+    for (int b = 0; b < T / 4; b++) {
+        const uint32_t q = pq[b];
+        const uint32_t k1 = (uint32_t)wb[q & 0xffu] | ((uint32_t)wb[(q >> 8) & 0xffu] << 8) |
+                            ((uint32_t)wb[(q >> 16) & 0xffu] << 16) | ((uint32_t)wb[q >> 24] << 24);
+        // '0'..'9' in every byte: high nibble 3, low nibble + 6 does not carry into bit 4
+        dig = dig && (k1 & 0xf0f0f0f0u) == 0x30303030u && (((k1 & 0x0f0f0f0fu) + 0x06060606u) & 0x10101010u) == 0u;
+        h = mm_h(h, k1);
+    }
+    h ^= mm_k((uint32_t)('0' + p));
+    all_digits = dig;
+    return mm_fin(h, T + 1);
+}
+
 // A pattern made of consecutive positions needs no gather: cw[i] holds the codes of bases i..i+3 packed into one
 // byte (= the table index of the block that starts at base i), so a block costs one ds_read_u8 with an immediate
 // offset and one table read.  wbw = cw + window base + first position of the run.
@@ -268,7 +290,8 @@ __device__ __forceinline__ void walk_fragment(const Batch &B, const Geom &G, uin
     const uint32_t len = fr.len;
     const uint8_t *src = fr.src;
     const int k = G.k, P = G.P, t = G.t;
-    const bool fast16 = (t == 16) && (P <= 10) && !raw;
+    const bool fast16 = (t == 16) && (P <= 10) && !raw;   // 2-bit packed: table-driven
+    const bool raw16 = (t == 16) && (P <= 10) && raw;      // text: murmur over letters in registers
     const bool digit_rule = raw && !G.hash_all;
     uint32_t fill = 0;
     const uint32_t S = G.reverse ? 2u : 1u;
@@ -289,6 +312,17 @@ __device__ __forceinline__ void walk_fragment(const Batch &B, const Geom &G, uin
                     pq[b] = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint32_t *>(pp)[b]);
                 for (uint32_t wl = lane; wl < cnt; wl += WAVE)
                     hb[fill + wl * (uint32_t)P + (uint32_t)p] = hash_name_tab<16>(sq + base_of(wl), pq, p, tab) & mask;
+            } else if (raw16) {
+                uint32_t pq[4];
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                    pq[b] = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint32_t *>(pp)[b]);
+                for (uint32_t wl = lane; wl < cnt; wl += WAVE) {
+                    bool all_digits;
+                    uint32_t h = hash_name_ascii<16>(sq + base_of(wl), pq, p, all_digits) & mask;
+                    if (digit_rule && all_digits) h = hash_name_generic(sq + base_of(wl), pp, t, p, true, mask);
+                    hb[fill + wl * (uint32_t)P + (uint32_t)p] = h;
+                }
             } else {
                 for (uint32_t wl = lane; wl < cnt; wl += WAVE)
                     hb[fill + wl * (uint32_t)P + (uint32_t)p] = hash_name_generic(sq + base_of(wl), pp, t, p, digit_rule, mask);

@@ -431,13 +431,17 @@ def test_run_patterns_and_unsorted_rows_against_oracle(amd, eng, oracle):
         pos = pos.astype(np.int32)
         eng.set_patterns(pos, k)
         lens = [0, k - 1, k, k + 1, k + 62, k + 63, k + 64, 199, 200, 255, 256, 257, 300, 1000]
-        seqs = [bytes(rng.choice(ACGT, size=L)) for L in lens] + [b"ACGTNNNNacgt" * 30, b"acgt" * 70]
-        for reverse in (False, True):
+        # text fragments (register murmur path), incl. all-digit names that `--hash strings` reads as numbers
+        seqs = [bytes(rng.choice(ACGT, size=L)) for L in lens] + [b"ACGTNNNNacgt" * 30, b"acgt" * 70, b"0123456789" * 30,
+                                                                  b"00000000000000000000ACGT1234567890123456789" * 8]
+        for reverse, hash_all in ((False, False), (True, False), (True, True)):
+            eng.set_vw_options(hash_all=hash_all)
             batch = eng.upload(amd.PackedReads.from_sequences(seqs))
             idx, off = eng.features(batch, reverse, 31)
-            oidx, ooff = oracle.features_batch(seqs, k, pos, reverse, 31)
+            oidx, ooff = oracle.features_batch(seqs, k, pos, reverse, 31, hash_all=hash_all)
             assert np.array_equal(off.cpu().numpy().view(np.uint64), ooff), (k, pos[0, 0], reverse)
-            assert np.array_equal(_u32(idx), oidx), (k, pos[0, 0], reverse)
+            assert np.array_equal(_u32(idx), oidx), (k, pos[0, 0], reverse, hash_all)
+    eng.set_vw_options()
 
 
 def test_emit_never_writes_past_out_cap(amd, eng, oracle, golden_dir):
