@@ -233,6 +233,15 @@ def train(ref_dir, model_dir, args, engine=None):
     genome_len = [len(s) for _, s in records]
     genome_taxid = [taxid_lines[g] if g < len(taxid_lines) else "" for g in range(len(records))]
 
+    # Several passes (reference opal.py:316-320: `--cache_file ... --passes N` on the ONE vw process that is fed every
+    # batch): vw replays its cache, i.e. the whole stream of all batches in the order it arrived, N-1 more times.
+    # With more than one pass vw also sets aside every 10th example of the stream (holdout_period 10) in ALL passes,
+    # keeps the regressor of the pass with the lowest holdout loss and stops after 3 passes without improvement
+    # (early_terminate 3).  [VW-unverified: documented vw behaviour, no vw here to pin it]
+    multipass = num_passes > 1
+    HOLDOUT_PERIOD, EARLY_TERMINATE = 10, 3
+    stream = []                                              # per batch: (train views, labels, holdout views, labels)
+    seen = 0
     seed = 420
     rng = Rng()
     for i in range(num_batches):
@@ -257,17 +266,51 @@ def train(ref_dir, model_dir, args, engine=None):
         print("Getting training set ...")
         print("Shuffling training set ...")
         perm = rng.shuffle_perm(n_frag).astype(np.int64)      # random.shuffle on the same stream (reference opal.py:363)
-        vwid = np.ascontiguousarray(vwid[perm])
-        batch = genomes.fragments(fpos[perm], fgen[perm], frag_length)
+        vwid, fpos, fgen = np.ascontiguousarray(vwid[perm]), fpos[perm], fgen[perm]
+        held = (np.arange(seen + 1, seen + n_frag + 1) % HOLDOUT_PERIOD == 0) if multipass else np.zeros(n_frag, dtype=bool)
+        seen += n_frag
+        keep = ~held
+        batch = genomes.fragments(fpos[keep], fgen[keep], frag_length)
+        y = np.ascontiguousarray(vwid[keep])
         print("Training on the GPU ...")
         sys.stdout.flush()
-        for p in range(max(1, num_passes)):
-            pred = eng.train_batch(batch, vwid, reverse, eta=0.5, l1=lambda1, l2=lambda2, want_pred=True)
-            err = float((pred.cpu().numpy() != vwid).mean()) if n_frag else 0.0
-            msg = "batch %d pass %d: %d examples, progressive error %.4f" % (i, p, n_frag, err)
+        pred = eng.train_batch(batch, y, reverse, eta=0.5, l1=lambda1, l2=lambda2, want_pred=True)
+        err = float((pred.cpu().numpy() != y).mean()) if y.size else 0.0
+        msg = "batch %d pass 0: %d examples, progressive error %.4f" % (i, y.size, err)
+        print(msg)
+        log.write(msg + "\n")
+        if multipass:
+            stream.append((batch, y, genomes.fragments(fpos[held], fgen[held], frag_length), np.ascontiguousarray(vwid[held])))
+    w = None
+    if multipass:
+        def holdout_error():
+            wrong = total = 0
+            for _, _, hb, hy in stream:
+                if hy.size:
+                    cls, _ = eng.predict(hb, reverse)
+                    wrong += int((cls.cpu().numpy() != hy).sum())
+                    total += hy.size
+            return wrong / total if total else 0.0
+        best = holdout_error()
+        w = eng.get_weights()
+        log.write("pass 0: holdout error %.4f\n" % best)
+        no_win = 0
+        for p in range(1, num_passes):
+            for batch, y, _, _ in stream:
+                eng.train_batch(batch, y, reverse, eta=0.5, l1=lambda1, l2=lambda2)
+            e = holdout_error()
+            msg = "pass %d: holdout error %.4f" % (p, e)
             print(msg)
             log.write(msg + "\n")
-    w = eng.get_weights()
+            if e < best:
+                best, w, no_win = e, eng.get_weights(), 0
+            else:
+                no_win += 1
+                if no_win == EARLY_TERMINATE:
+                    log.write("no improvement in %d passes: stopping, keeping the best regressor\n" % EARLY_TERMINATE)
+                    break
+    if w is None:
+        w = eng.get_weights()
     nnz = model_io.save_model(final_model_file, w, num_labels, bits)
     log.write("saved %s (%d non-zero weights)\n" % (final_model_file, nnz))
     log.close()

@@ -154,6 +154,48 @@ def test_cli_simulate_pipeline(amd, tmp_path, capsys):
     assert "micro = %.4f" % micro in capsys.readouterr().out
 
 
+def test_cli_train_multipass_holdout_and_early_stop(amd, tmp_path):
+    """--num-passes > 1 (reference opal.py:316-320: vw --cache_file --passes N on the whole stream): the stream of all
+    batches is replayed, every 10th example is held out, the log carries one holdout line per pass and training stops
+    after 3 passes without improvement; the saved model still classifies the training genomes."""
+    import argparse
+    from opal_amd import opal, model as model_io
+    rng = np.random.default_rng(19)
+    K = 5
+    genomes = _make_genomes(rng, K, 20_000, 0.30)
+    os.makedirs(tmp_path / "train")
+    with open(tmp_path / "train" / "A1.fasta", "w") as f:
+        for i, g in enumerate(genomes):
+            f.write(">g%d\n%s\n" % (i, g.decode()))
+    with open(tmp_path / "train" / "A1.taxid", "w") as f:
+        f.write("".join("t%d\n" % i for i in range(K)))
+    np.random.seed(3)
+    args = argparse.Namespace(frag_length=200, coverage=3.0, kmer=64, row_weight=16, hierarchical_weight=-1, num_hash=1,
+                              num_batches=2, num_passes=8, bits=22, lambda1=0.0, lambda2=0.0, reverse_complement=True)
+    opal.train(str(tmp_path / "train"), str(tmp_path / "model"), args)
+    log = open(tmp_path / "model" / "vw-model_vwps.log").read().splitlines()
+    first = [l for l in log if " pass 0: " in l and l.startswith("batch")]
+    assert len(first) == 2
+    n_trained = sum(int(l.split(":")[1].split()[0]) for l in first)
+    assert n_trained == 2 * 1500 - (2 * 1500) // 10                   # every 10th example of the stream is held out
+    hold = [l for l in log if "holdout error" in l]
+    assert 2 <= len(hold) <= 8 and hold[0].startswith("pass 0:")
+    errs = [float(l.rsplit(" ", 1)[1]) for l in hold]
+    if len(hold) < 8:                                                  # stopped early: 3 passes in a row without a new best
+        assert any("no improvement in 3 passes" in l for l in log)
+        assert min(errs[-3:]) >= min(errs[:-3])
+    eng = amd.Engine(0)
+    with open(tmp_path / "model" / "patterns.txt") as f:
+        pos = amd.parse_patterns(f.readlines(), 64)
+    eng.set_patterns(pos, 64)
+    model_io.load_model(str(tmp_path / "model" / "vw-model_final.model"), eng)
+    frags = [g[a:a + 200] for g in genomes for a in range(0, 19_000, 1000)]
+    cls, _ = eng.predict(eng.upload(amd.PackedReads.from_sequences(frags)), True)
+    truth = np.repeat(np.arange(1, K + 1), 19)
+    assert (cls.cpu().numpy() == truth).mean() > 0.95
+    eng.close()
+
+
 def test_gpu_eval_counts_match_host(amd, oracle, tmp_path, capsys):
     from opal_amd import opal
     rng = np.random.default_rng(1)
