@@ -131,11 +131,21 @@ class GenomeSet:
     """Genomes resident in HBM (packed once); fragments are (offset, length) views into them: sampling a batch
     uploads 12 bytes per fragment instead of its bases (zero-copy `drawfrag`, reference util/drawfrag.py:38-39)."""
 
-    def __init__(self, engine, pr: PackedReads):
+    def __init__(self, engine, pr: PackedReads, dev=None):
+        """pr: host-side batch (only its off/len arrays are used when `dev`, the device copy, is given)."""
         self.engine = engine
         self.host = pr
-        self.dev = engine.upload(pr)
+        self.dev = dev if dev is not None else engine.upload(pr)
         self.lengths = (pr.len & np.uint32(0x7FFFFFFF)).astype(np.uint64)
+
+    @staticmethod
+    def from_fasta(engine, path):
+        """Genomes straight from a FASTA file through the GPU ingest (the host never walks the sequence text);
+        same records as fasta_reader over open(path, 'r') (reference util/fasta_functions.py:9-43)."""
+        dev = engine.ingest_fasta(path)
+        off = dev.off[:dev.n].cpu().numpy().view(np.uint64)
+        ln = dev.len[:dev.n].cpu().numpy().view(np.uint32)
+        return GenomeSet(engine, PackedReads(None, off, ln), dev)
 
     def fragments(self, pos, gen, frag_len: int) -> "DeviceBatch":
         """pos, gen: arrays from Rng.sample_positions (position inside the genome, genome index)."""

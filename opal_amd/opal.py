@@ -19,8 +19,7 @@ import numpy as np
 
 from . import drawfrag, fasta2skm, ldpc
 from . import model as model_io
-from .engine import Engine, GenomeSet, PackedReads, Rng, parse_patterns
-from .fasta_functions import fasta_reader
+from .engine import Engine, GenomeSet, Rng, parse_patterns
 from .shard import gather_in_rank_order, shard_range
 
 __version__ = "1.0.0"
@@ -223,15 +222,14 @@ def train(ref_dir, model_dir, args, engine=None):
     log = open(model_prefix + "_vwps.log", "w")
     log.write("opal_amd learner: oaa=%d bits=%d l1=%g l2=%g passes=%d\n" % (num_labels, bits, lambda1, lambda2, num_passes))
 
-    with open(fasta, "r", encoding="latin-1") as f:
-        records = list(fasta_reader(f))
     with open(taxids, "r") as f:
         taxid_lines = [l.rstrip("\n") for l in f]
-    # genomes are packed once and stay in HBM; a training batch is only (offset, length, label) per fragment:
-    # the fragments drawfrag would write to train.batch-i.fasta are views into the resident genomes
-    genomes = GenomeSet(eng, PackedReads.from_sequences([s.encode("latin-1") for _, s in records]))
-    genome_len = [len(s) for _, s in records]
-    genome_taxid = [taxid_lines[g] if g < len(taxid_lines) else "" for g in range(len(records))]
+    # genomes are split into records and packed on the GPU (opal_ingest_fasta = fasta_reader's records) and stay in
+    # HBM; a training batch is only (offset, length, label) per fragment: the fragments drawfrag would write to
+    # train.batch-i.fasta are views into the resident genomes
+    genomes = GenomeSet.from_fasta(eng, fasta)
+    genome_len = [int(x) for x in genomes.lengths]
+    genome_taxid = [taxid_lines[g] if g < len(taxid_lines) else "" for g in range(len(genome_len))]
 
     # Several passes (reference opal.py:316-320: `--cache_file ... --passes N` on the ONE vw process that is fed every
     # batch): vw replays its cache, i.e. the whole stream of all batches in the order it arrived, N-1 more times.
