@@ -407,6 +407,24 @@ __device__ __forceinline__ void vadd(float &a, const float &b) { a += b; }
 __device__ __forceinline__ void vadd(float2 &a, const float2 &b) { a.x += b.x; a.y += b.y; }
 __device__ __forceinline__ void vadd(float4 &a, const float4 &b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 
+// streaming (non-temporal) load of VEC floats: table rows are read once and never again.  Measured on the predict
+// kernel: 133.3 -> 122.1 ms at K=356 and 275 -> 253 ms at K=1564 (the default policy tops out near 6.3 TB/s of HBM
+// traffic, nt reaches 6.9)
+template <int VEC> __device__ __forceinline__ typename VecOf<VEC>::type nt_load(const float *p);
+template <> __device__ __forceinline__ float nt_load<1>(const float *p) { return __builtin_nontemporal_load(p); }
+template <> __device__ __forceinline__ float2 nt_load<2>(const float *p)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(p));
+    return make_float2(v.x, v.y);
+}
+template <> __device__ __forceinline__ float4 nt_load<4>(const float *p)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // Streams rows hb[0..nf) of the padded weight table into acc.  hb[nf .. nf+U) must be readable (dummy rows:
 // they are loaded and never consumed).  loff[j] = this lane's float offset inside a row for vector j (already
 // clamped into the row, so every load is unconditional).
@@ -424,8 +442,8 @@ __device__ __forceinline__ void stream_rows(const float *__restrict__ tab, const
         return (idx * K) & mask;  // (h*K) mod 2^b, b <= 32: low 32 bits suffice
     };
     auto ld = [&](uint32_t row, uint32_t lo) -> V {
-        if constexpr (WRAP) return *reinterpret_cast<const V *>(tab + (size_t)((row + lo) & mask));
-        else return *reinterpret_cast<const V *>(tab + (size_t)row + lo);
+        if constexpr (WRAP) return *reinterpret_cast<const V *>(tab + (size_t)((row + lo) & mask));   // trainer: nt measured 3 % slower
+        else return nt_load<VEC>(tab + (size_t)row + lo);
     };
 #pragma unroll
     for (int u = 0; u < U; u++) {
