@@ -231,6 +231,38 @@ def test_properties_at_scale(amd, eng, oracle, golden_dir):
     eng.set_vw_options()
 
 
+def test_correctness_run_with_injected_n_and_lowercase(amd, eng, oracle, golden_dir):
+    """the throughput inputs are upper-case ACGT; this is the separate correctness run with 0.1 % of the
+    bases replaced by N / lower-case letters, so a batch mixes 2-bit packed fragments (table-driven hash) with text
+    fragments (register murmur, the reference's RC quirk).  Emit and predict must equal the oracle on every fragment."""
+    rng = np.random.default_rng(77)
+    n, L, K, bits = 60_000, 200, 356, 22
+    pos = _patterns(amd, golden_dir, "patterns_k64_t16_m1_s7.txt", 64)
+    eng.set_patterns(pos, 64)
+    text = ACGT[rng.integers(0, 4, size=(n, L), dtype=np.uint8)]
+    hit = rng.random((n, L)) < 0.001
+    repl = np.frombuffer(b"NnacgtRY", dtype=np.uint8)[rng.integers(0, 8, size=int(hit.sum()))]
+    text[hit] = repl
+    raw_rows = hit.any(axis=1)
+    assert 0.1 < raw_rows.mean() < 0.3                               # ~18 % of the fragments carry at least one
+    blob = np.concatenate([text.reshape(-1), np.zeros(1, dtype=np.uint8)])
+    soff = (np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
+    pr = amd.PackedReads.from_blob(blob, soff)
+    assert np.array_equal((pr.len & np.uint32(0x80000000)) != 0, raw_rows)
+    batch = eng.upload(pr)
+    idx, off = eng.features(batch, True, 31)
+    oidx, ooff = oracle.features_batch((blob, soff), 64, pos, True, 31, nthreads=0)
+    assert np.array_equal(off.cpu().numpy().view(np.uint64), ooff)
+    assert np.array_equal(_u32(idx), oidx)
+    w = (rng.standard_normal(1 << bits) * 0.05).astype(np.float32)
+    eng.load_weights(w, K, bits)
+    eng.set_vw_options()
+    cls, sc = eng.predict(batch, True, want_scores=True)
+    m = 6000
+    ocls, osc, _ = oracle.predict((blob[:m * L + 1], soff[:m + 1]), 64, pos, True, w, K, bits, nthreads=0)
+    assert np.array_equal(sc.cpu().numpy()[:m], osc) and np.array_equal(cls.cpu().numpy()[:m], ocls)
+
+
 def test_zero_copy_fragments_from_resident_genomes(amd, eng, oracle, golden_dir):
     """drawfrag on the GPU side: fragments are views (genome offset + position) into genomes packed once in HBM;
     features and predictions equal those of the explicitly cut fragments (reference util/drawfrag.py:38-39)."""
