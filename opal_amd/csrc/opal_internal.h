@@ -26,6 +26,7 @@ struct opal_ctx {
     int hash_all = 0, add_constant = 1, clip = 1;
     float min_label = -1.0f, max_label = 1.0f;
     // scratch for the offsets scan
+    unsigned long long *d_queue = nullptr;   // work-queue counter of the predict kernel (allocated with the ctx)
     uint64_t *d_block_sums = nullptr;
     uint64_t block_sums_cap = 0;
     // scratch of the FASTA ingest (grown on demand)

@@ -107,7 +107,7 @@ template <int VEC, int NV, int U>
 __global__ __launch_bounds__(BLOCK) void predict_kernel(Batch B, Geom G, const float *__restrict__ tab, uint32_t mask, int K,
                                                          int add_constant, uint32_t const_idx, int clip, float min_label,
                                                          float max_label, int32_t *__restrict__ out_class,
-                                                         float *__restrict__ out_scores)
+                                                         float *__restrict__ out_scores, unsigned long long *__restrict__ queue)
 {
     using V = typename VecOf<VEC>::type;
     constexpr int CH = WAVE * VEC * NV;  // classes per chunk
@@ -118,10 +118,22 @@ __global__ __launch_bounds__(BLOCK) void predict_kernel(Batch B, Geom G, const f
     const int wv = threadIdx.x / WAVE;
     fill_kmer4_table(s_tab);
     uint32_t *hb = s_hb[wv];
-    const uint64_t nwaves = (uint64_t)gridDim.x * WPB;
     const uint32_t Ku = (uint32_t)K;
+    // Fragments are handed out QCHUNK at a time through a counter (zeroed before the launch): a wave that drew short
+    // fragments simply draws more, so ragged batches keep every wave busy to the end.  One atomic per QCHUNK fragments
+    // and wave (one per fragment measurably contends on the counter at 8M fragments/s); every wave leaves as soon as
+    // the counter passes n.
+    constexpr uint64_t QCHUNK = 8;
+    auto next_chunk = [&]() -> uint64_t {
+        unsigned long long v = 0;
+        if (lane == 0) v = atomicAdd(queue, (unsigned long long)QCHUNK);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+        return ((uint64_t)hi << 32) | lo;
+    };
 
-    for (uint64_t frag = (uint64_t)blockIdx.x * WPB + wv; frag < B.n; frag += nwaves) {
+    for (uint64_t q0 = next_chunk(); q0 < B.n; q0 = next_chunk())
+    for (uint64_t frag = q0; frag < min(q0 + QCHUNK, B.n); frag++) {
         float best = 0.0f;
         uint32_t best_c = 0xffffffffu;
         for (uint32_t c0 = 0; c0 < Ku; c0 += CH) {
@@ -336,6 +348,7 @@ extern "C" int opal_ctx_create(int device_id, void *stream, opal_ctx **out)
     // NULL is HIP's default (null) stream, which is also what torch.cuda.current_stream() is unless the caller
     // switched streams: work enqueued here is then ordered with the caller's copies without extra events.
     ctx->stream = (hipStream_t)stream;
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_queue, 256);
     if (e != hipSuccess) {
         std::string m = std::string("opal_ctx_create: ") + hipGetErrorString(e);
         delete ctx;
@@ -357,6 +370,7 @@ extern "C" int opal_ctx_destroy(opal_ctx *ctx)
     if (ctx->ing_seq) (void)hipFree(ctx->ing_seq);
     if (ctx->ing_rec) (void)hipFree(ctx->ing_rec);
     if (ctx->d_block_sums) (void)hipFree(ctx->d_block_sums);
+    if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     delete ctx;
     return OPAL_OK;
 }
@@ -550,7 +564,8 @@ extern "C" int opal_predict(opal_ctx *ctx, const uint8_t *d_reads, uint64_t read
     const float *tab = ctx->d_w;
     int K = ctx->K, addc = ctx->add_constant, clip = ctx->clip;
     float minl = ctx->min_label, maxl = ctx->max_label;
-    void *args[] = {&B, &G, &tab, (void *)&mask, &K, &addc, (void *)&const_idx, &clip, &minl, &maxl, &d_out_class, &d_out_scores};
+    OPAL_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), ctx->stream));
+    void *args[] = {&B, &G, &tab, (void *)&mask, &K, &addc, (void *)&const_idx, &clip, &minl, &maxl, &d_out_class, &d_out_scores, &ctx->d_queue};
     OPAL_HIP_CHECK(ctx, hipLaunchKernel(v.fn, dim3(grid), dim3(BLOCK), args, 0, ctx->stream));
     return OPAL_OK;
 }
