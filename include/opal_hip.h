@@ -124,7 +124,9 @@ int opal_feature_names(opal_ctx *ctx, const uint8_t *d_reads, uint64_t reads_byt
 
 /* Fused predict. Replaces fasta2skm.main_generator piped into `vw -t -i model -p preds` (opal.py:449-469):
  * d_out_class[i] = 1-based VW class of fragment i (what vw writes to the -p file), d_out_scores (optional,
- * may be NULL) receives the K per-class scores of every fragment, row-major [n][K].                         */
+ * may be NULL) receives the K per-class scores of every fragment, row-major [n][K].
+ * Asynchronous on the ctx stream; calls on one ctx are ordered by that stream (they share the ctx's work-queue
+ * counter), so use one ctx per concurrent stream.                                                             */
 int opal_predict(opal_ctx *ctx, const uint8_t *d_reads, uint64_t reads_bytes, const uint64_t *d_frag_off,
                  const uint32_t *d_frag_len, uint64_t n, int reverse, int32_t *d_out_class, float *d_out_scores);
 
