@@ -113,8 +113,16 @@ def main():
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:      # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
+        # OPAL_DIST_BACKEND=gloo is for rehearsing the N>1 path on a box with fewer GPUs than ranks (ranks then share
+        # devices round-robin); the driver's runs use nccl (= RCCL), one rank per GPU
+        backend = os.environ.get("OPAL_DIST_BACKEND", "nccl")
+        if backend != "nccl":
+            local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     wl = dict(WORKLOADS[args.workload])
     if args.nfrag:
@@ -202,7 +210,7 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0 - t_pre
     if dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
