@@ -149,10 +149,11 @@ def _dist():
         return None, 0, 1, 0
     import torch
     import torch.distributed as dist
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # ranks map to GPUs round-robin (one rank per GPU on a full node).  The data path has no collective; the only
+    # exchange is rank 0 collecting the class ids from host memory, so the process group is gloo, not RCCL.
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
     if not dist.is_initialized():
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group(os.environ.get("OPAL_DIST_BACKEND", "gloo"))
     return dist, dist.get_rank(), dist.get_world_size(), local
 
 

@@ -258,3 +258,44 @@ def test_saturated_classes_skip_updates_but_keep_the_rule(amd, oracle, golden_di
     assert np.allclose(gw, w, rtol=2e-4, atol=1e-6)
     assert (gw != w0).sum() > 0 and (gw != w0).mean() < 0.5      # only the true classes' slots moved
     eng.close()
+
+
+def _predict_rank(rank, world, port, model_dir, test_dir, out_dir):
+    import argparse
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from opal_amd import opal
+    opal.predict(model_dir, test_dir, out_dir, argparse.Namespace(kmer=64, reverse_complement=True))
+
+
+def test_cli_predict_two_ranks_equals_one(amd, tmp_path):
+    """`opal.py predict` launched as two ranks (here both on the one GPU of the box): each scores its contiguous shard,
+    rank 0 writes the files; the result equals the single-process run byte for byte."""
+    import argparse
+    import socket
+    import torch.multiprocessing as mp
+    from opal_amd import opal, model as model_io
+    rng = np.random.default_rng(23)
+    K, bits = 9, 18
+    os.makedirs(tmp_path / "model")
+    os.makedirs(tmp_path / "test")
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "golden", "patterns_k64_t16_m1_s7.txt")) as f:
+        (tmp_path / "model" / "patterns.txt").write_text(f.read())
+    (tmp_path / "model" / "vw-dico.txt").write_text("".join("tax%d\t%d\n" % (i, i) for i in range(1, K + 1)))
+    w = (rng.standard_normal(1 << bits) * 0.05).astype(np.float32)
+    model_io.save_model(str(tmp_path / "model" / "vw-model_final.model"), w, K, bits)
+    with open(tmp_path / "test" / "reads.fasta", "w") as f:
+        for i in range(1001):
+            f.write(">r%d\n%s\n" % (i, bytes(ACGT[rng.integers(0, 4, size=int(rng.integers(40, 300)))]).decode()))
+    args = argparse.Namespace(kmer=64, reverse_complement=True)
+    opal.predict(str(tmp_path / "model"), str(tmp_path / "test"), str(tmp_path / "one"), args)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_predict_rank, args=(2, port, str(tmp_path / "model"), str(tmp_path / "test"), str(tmp_path / "two")), nprocs=2, join=True)
+    for name in ("test.fragments-db.preds.vw", "test.fragments-db.preds.taxid"):
+        a, b = (tmp_path / "one" / name).read_bytes(), (tmp_path / "two" / name).read_bytes()
+        assert a == b and a.count(b"\n") == 1001
