@@ -32,9 +32,24 @@ __device__ __forceinline__ uint64_t feature_count(uint32_t len_word, const Geom 
     return len >= (uint32_t)G.k ? (uint64_t)(len - (uint32_t)G.k + 1u) * (uint64_t)G.P * (G.reverse ? 2u : 1u) : 0ull;
 }
 
+// Work queue shared by the emit and predict kernels: fragments are handed out QCHUNK at a time through a counter that
+// the entry point zeroes before the launch; a wave that drew short fragments simply draws more, so ragged batches
+// keep every wave busy to the end.  One atomic per QCHUNK fragments and wave (one per fragment measurably contends on
+// the counter at 8M fragments/s); every wave leaves as soon as the counter passes n.
+constexpr uint64_t QCHUNK = 8;
+__device__ __forceinline__ uint64_t next_chunk(unsigned long long *queue, int lane)
+{
+    unsigned long long v = 0;
+    if (lane == 0) v = atomicAdd(queue, (unsigned long long)QCHUNK);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // ------------------------------------------------------------------------------------------ emit kernels
 __global__ __launch_bounds__(BLOCK) void emit_idx_kernel(Batch B, Geom G, uint32_t mask, const uint64_t *__restrict__ out_off,
-                                                          uint32_t *__restrict__ out_idx, uint64_t out_cap)
+                                                          uint32_t *__restrict__ out_idx, uint64_t out_cap,
+                                                          unsigned long long *__restrict__ queue)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_seq[WPB][2 * SEQB];
     __shared__ __attribute__((aligned(16))) uint32_t s_hb[WPB][HB + HB_PAD];
@@ -42,8 +57,8 @@ __global__ __launch_bounds__(BLOCK) void emit_idx_kernel(Batch B, Geom G, uint32
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = threadIdx.x / WAVE;
     fill_kmer4_table(s_tab);
-    const uint64_t nwaves = (uint64_t)gridDim.x * WPB;
-    for (uint64_t frag = (uint64_t)blockIdx.x * WPB + wv; frag < B.n; frag += nwaves) {
+    for (uint64_t q0 = next_chunk(queue, lane); q0 < B.n; q0 = next_chunk(queue, lane))
+    for (uint64_t frag = q0; frag < min(q0 + QCHUNK, B.n); frag++) {
         const uint64_t o0 = out_off[frag];
         if (o0 > out_cap || feature_count(B.len[frag], G) > out_cap - o0) continue;   // never write outside out_idx
         uint32_t *dst = out_idx + o0;
@@ -119,20 +134,7 @@ __global__ __launch_bounds__(BLOCK) void predict_kernel(Batch B, Geom G, const f
     fill_kmer4_table(s_tab);
     uint32_t *hb = s_hb[wv];
     const uint32_t Ku = (uint32_t)K;
-    // Fragments are handed out QCHUNK at a time through a counter (zeroed before the launch): a wave that drew short
-    // fragments simply draws more, so ragged batches keep every wave busy to the end.  One atomic per QCHUNK fragments
-    // and wave (one per fragment measurably contends on the counter at 8M fragments/s); every wave leaves as soon as
-    // the counter passes n.
-    constexpr uint64_t QCHUNK = 8;
-    auto next_chunk = [&]() -> uint64_t {
-        unsigned long long v = 0;
-        if (lane == 0) v = atomicAdd(queue, (unsigned long long)QCHUNK);
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-        return ((uint64_t)hi << 32) | lo;
-    };
-
-    for (uint64_t q0 = next_chunk(); q0 < B.n; q0 = next_chunk())
+    for (uint64_t q0 = next_chunk(queue, lane); q0 < B.n; q0 = next_chunk(queue, lane))
     for (uint64_t frag = q0; frag < min(q0 + QCHUNK, B.n); frag++) {
         float best = 0.0f;
         uint32_t best_c = 0xffffffffu;
@@ -514,7 +516,8 @@ extern "C" int opal_features(opal_ctx *ctx, const uint8_t *d_reads, uint64_t rea
     int grid = 1;
     rc = grid_for(ctx, (const void *)&emit_idx_kernel, n, &grid);
     if (rc) return rc;
-    hipLaunchKernelGGL(emit_idx_kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, B, G, mask, d_out_off, d_out_idx, out_cap);
+    OPAL_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(emit_idx_kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, B, G, mask, d_out_off, d_out_idx, out_cap, ctx->d_queue);
     OPAL_HIP_CHECK(ctx, hipGetLastError());
     return OPAL_OK;
 }
