@@ -392,6 +392,20 @@ __device__ __forceinline__ void walk_fragment(const Batch &B, const Geom &G, uin
     flush(fill);
 }
 
+// Work queue shared by the emit, predict and (concurrent-mode) train kernels: fragments are handed out QCHUNK at a time through a counter that
+// the entry point zeroes before the launch; a wave that drew short fragments simply draws more, so ragged batches
+// keep every wave busy to the end.  One atomic per QCHUNK fragments and wave (one per fragment measurably contends on
+// the counter at 8M fragments/s); every wave leaves as soon as the counter passes n.
+constexpr uint64_t QCHUNK = 8;
+__device__ __forceinline__ uint64_t next_chunk(unsigned long long *queue, int lane, uint64_t chunk = QCHUNK)
+{
+    unsigned long long v = 0;
+    if (lane == 0) v = atomicAdd(queue, (unsigned long long)chunk);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // ------------------------------------------------------------------------------------------ phase S
 template <int VEC> struct VecOf;
 template <> struct VecOf<1> { using type = float; };

@@ -32,20 +32,6 @@ __device__ __forceinline__ uint64_t feature_count(uint32_t len_word, const Geom 
     return len >= (uint32_t)G.k ? (uint64_t)(len - (uint32_t)G.k + 1u) * (uint64_t)G.P * (G.reverse ? 2u : 1u) : 0ull;
 }
 
-// Work queue shared by the emit and predict kernels: fragments are handed out QCHUNK at a time through a counter that
-// the entry point zeroes before the launch; a wave that drew short fragments simply draws more, so ragged batches
-// keep every wave busy to the end.  One atomic per QCHUNK fragments and wave (one per fragment measurably contends on
-// the counter at 8M fragments/s); every wave leaves as soon as the counter passes n.
-constexpr uint64_t QCHUNK = 8;
-__device__ __forceinline__ uint64_t next_chunk(unsigned long long *queue, int lane)
-{
-    unsigned long long v = 0;
-    if (lane == 0) v = atomicAdd(queue, (unsigned long long)QCHUNK);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
-
 // ------------------------------------------------------------------------------------------ emit kernels
 __global__ __launch_bounds__(BLOCK) void emit_idx_kernel(Batch B, Geom G, uint32_t mask, const uint64_t *__restrict__ out_off,
                                                           uint32_t *__restrict__ out_idx, uint64_t out_cap,

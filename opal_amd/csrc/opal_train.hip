@@ -52,7 +52,7 @@ template <int VEC, int NV, int U>
 __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__restrict__ w, float *__restrict__ g2,
                                                        uint32_t mask, int K, uint32_t const_idx,
                                                        const int32_t *__restrict__ labels, TrainArgs ta,
-                                                       int32_t *__restrict__ out_pred)
+                                                       int32_t *__restrict__ out_pred, unsigned long long *__restrict__ queue)
 {
     using V = typename VecOf<VEC>::type;
     constexpr int CH = WAVE * VEC * NV;
@@ -63,15 +63,13 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
     const int wv = threadIdx.x / WAVE;
     fill_kmer4_table(s_tab);
     uint32_t *hb = s_hb[wv];
-    uint64_t nwaves = (uint64_t)gridDim.x * WPB;
-    uint64_t first = (uint64_t)blockIdx.x * WPB + wv;
-    if (ta.sequential) {
-        if (first != 0) return;
-        nwaves = 1;
-    }
+    if (ta.sequential && ((uint64_t)blockIdx.x * WPB + wv) != 0) return;    // one wave, examples in order
     const uint32_t Ku = (uint32_t)K;
 
-    for (uint64_t frag = first; frag < B.n; frag += nwaves) {
+    // concurrent mode: examples are drawn one at a time from the work queue (an example takes 0.2-4 ms, so the
+    // atomic is free and a coarser hand-out only lengthens the tail); sequential mode: 0, 1, 2, ...
+    for (uint64_t frag = ta.sequential ? 0 : next_chunk(queue, lane, 1); frag < B.n;
+         frag = ta.sequential ? frag + 1 : next_chunk(queue, lane, 1)) {
         const uint32_t label = (uint32_t)(labels[frag] - 1);   // VW class ids are 1-based
         float best = 0.0f;
         uint32_t best_c = 0xffffffffu;
@@ -441,7 +439,8 @@ extern "C" int opal_train_batch(opal_ctx *ctx, const uint8_t *d_reads, uint64_t 
     int phases = 3;
     if (const char *e = getenv("OPAL_TRAIN_PHASES")) phases = atoi(e);   // profiling experiments only
     TrainArgs ta{eta, l1, l2, ctx->min_label, ctx->max_label, sequential != 0, phases};
-    void *args[] = {&B, &G, &w, &g2, (void *)&mask, &K, (void *)&const_idx, &d_labels, &ta, &d_out_pred};
+    OPAL_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), ctx->stream));
+    void *args[] = {&B, &G, &w, &g2, (void *)&mask, &K, (void *)&const_idx, &d_labels, &ta, &d_out_pred, &ctx->d_queue};
     OPAL_HIP_CHECK(ctx, hipLaunchKernel(v.fn, dim3(grid), dim3(BLOCK), args, 0, ctx->stream));
     // keep the wrap padding coherent so that opal_predict can be called between batches
     return refresh_mirror(ctx);
