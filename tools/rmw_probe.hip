@@ -17,7 +17,8 @@ __device__ __forceinline__ uint32_t mix(uint32_t x)
 }
 
 // MODE 0 read, 1 write, 2 rmw (one table), 3 read table A + rmw table B (the shape of sweep 3),
-// 5 = read with non-temporal loads (what the predict kernel uses),
+// 5 = read with non-temporal loads (what the predict kernel uses), 6 = rmw with nt loads and nt stores, 7 = rmw with
+// plain loads and nt stores,
 // 4 = rmw that also rewrites (unchanged) the bytes of the row's first and last 128-B line that lie outside the
 // row, so that every line it dirties is dirtied completely
 template <int MODE, int U>
@@ -55,7 +56,8 @@ __global__ __launch_bounds__(256) void probe(float *__restrict__ a, float *__res
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 if (MODE == 0 || MODE == 2 || MODE == 3 || MODE == 4) va[u] = *reinterpret_cast<const float4 *>(a + (size_t)row[u] + c);
-                if (MODE == 5) {
+                if (MODE == 7) va[u] = *reinterpret_cast<const float4 *>(a + (size_t)row[u] + c);
+                if (MODE == 5 || MODE == 6) {
                     typedef float f4 __attribute__((ext_vector_type(4)));
                     const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(a + (size_t)row[u] + c));
                     va[u] = make_float4(t.x, t.y, t.z, t.w);
@@ -67,6 +69,11 @@ __global__ __launch_bounds__(256) void probe(float *__restrict__ a, float *__res
                 if (MODE == 0 || MODE == 5) { acc.x += va[u].x; acc.y += va[u].y; acc.z += va[u].z; acc.w += va[u].w; }
                 if (MODE == 1) *reinterpret_cast<float4 *>(a + (size_t)row[u] + c) = make_float4(1.f, 2.f, 3.f, (float)r0);
                 if (MODE == 2 || MODE == 4) { va[u].x += 1.f; va[u].y += 1.f; va[u].z += 1.f; va[u].w += 1.f; *reinterpret_cast<float4 *>(a + (size_t)row[u] + c) = va[u]; }
+                if (MODE == 6 || MODE == 7) {
+                    typedef float f4 __attribute__((ext_vector_type(4)));
+                    f4 t; t.x = va[u].x + 1.f; t.y = va[u].y + 1.f; t.z = va[u].z + 1.f; t.w = va[u].w + 1.f;
+                    __builtin_nontemporal_store(t, reinterpret_cast<f4 *>(a + (size_t)row[u] + c));
+                }
                 if (MODE == 3) { vb[u].x += va[u].x; vb[u].y += va[u].y; vb[u].z += va[u].z; vb[u].w += va[u].w; *reinterpret_cast<float4 *>(b + (size_t)row[u] + c) = vb[u]; }
             }
         }
@@ -97,7 +104,7 @@ static void run(float *a, float *b, float *sink, uint32_t mask, uint32_t K, int 
     const double units = (MODE == 0 || MODE == 1 || MODE == 5) ? 1 : (MODE == 3 ? 3 : 2);
     const double bytes = rows * K * 4.0 * units;
     printf("mode=%s U=%d waves/CU=%2d K=%u  %.2f ms  %.2f TB/s (%.0f row-units)\n",
-           MODE == 0 ? "read " : MODE == 1 ? "write" : MODE == 2 ? "rmw  " : MODE == 3 ? "r+rmw" : MODE == 4 ? "rmw+p" : "rd nt", U, blocks_per_cu * 4, K, ms, bytes / ms / 1e9, units);
+           MODE == 0 ? "read " : MODE == 1 ? "write" : MODE == 2 ? "rmw  " : MODE == 3 ? "r+rmw" : MODE == 4 ? "rmw+p" : MODE == 5 ? "rd nt" : MODE == 6 ? "rmwNN" : "rmw-N", U, blocks_per_cu * 4, K, ms, bytes / ms / 1e9, units);
     fflush(stdout);
     CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
 }
@@ -125,6 +132,8 @@ int main(int argc, char **argv)
         run<2, 4>(a, b, sink, mask, K, bpc, cus);
         run<2, 8>(a, b, sink, mask, K, bpc, cus);
         run<4, 4>(a, b, sink, mask, K, bpc, cus);
+        run<6, 4>(a, b, sink, mask, K, bpc, cus);
+        run<7, 4>(a, b, sink, mask, K, bpc, cus);
         run<3, 2>(a, b, sink, mask, K, bpc, cus);
         run<3, 4>(a, b, sink, mask, K, bpc, cus);
         run<3, 8>(a, b, sink, mask, K, bpc, cus);
