@@ -421,9 +421,10 @@ __device__ __forceinline__ void vadd(float &a, const float &b) { a += b; }
 __device__ __forceinline__ void vadd(float2 &a, const float2 &b) { a.x += b.x; a.y += b.y; }
 __device__ __forceinline__ void vadd(float4 &a, const float4 &b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 
-// streaming (non-temporal) load of VEC floats: table rows are read once and never again.  Measured on the predict
-// kernel: 133.3 -> 122.1 ms at K=356 and 275 -> 253 ms at K=1564 (the default policy tops out near 6.3 TB/s of HBM
-// traffic, nt reaches 6.9)
+// streaming (non-temporal) load of VEC floats, for tables far larger than the caches: rows are read once and never
+// again.  Measured on the predict kernel with the 8 GiB table: 133.3 -> 122.1 ms at K=356 and 275 -> 253 ms at K=1564
+// (the default policy tops out near 6.3 TB/s of HBM traffic, nt reaches 6.9).  Small tables keep the default policy:
+// they live in L2 / the Infinity Cache, which nt loads bypass (2^20 slots: 29.6 ms default, 72.6 ms nt).
 template <int VEC> __device__ __forceinline__ typename VecOf<VEC>::type nt_load(const float *p);
 template <> __device__ __forceinline__ float nt_load<1>(const float *p) { return __builtin_nontemporal_load(p); }
 template <> __device__ __forceinline__ float2 nt_load<2>(const float *p)
@@ -442,7 +443,7 @@ template <> __device__ __forceinline__ float4 nt_load<4>(const float *p)
 // Streams rows hb[0..nf) of the padded weight table into acc.  hb[nf .. nf+U) must be readable (dummy rows:
 // they are loaded and never consumed).  loff[j] = this lane's float offset inside a row for vector j (already
 // clamped into the row, so every load is unconditional).
-template <int VEC, int NV, int U, bool WRAP = false>
+template <int VEC, int NV, int U, bool WRAP = false, bool NT = false>
 __device__ __forceinline__ void stream_rows(const float *__restrict__ tab, const uint32_t *hb, uint32_t nf, uint32_t K,
                                             uint32_t mask, const uint32_t (&loff)[NV],
                                             typename VecOf<VEC>::type (&acc)[NV])
@@ -457,7 +458,8 @@ __device__ __forceinline__ void stream_rows(const float *__restrict__ tab, const
     };
     auto ld = [&](uint32_t row, uint32_t lo) -> V {
         if constexpr (WRAP) return *reinterpret_cast<const V *>(tab + (size_t)((row + lo) & mask));   // trainer: nt measured 3 % slower
-        else return nt_load<VEC>(tab + (size_t)row + lo);
+        else if constexpr (NT) return nt_load<VEC>(tab + (size_t)row + lo);
+        else return *reinterpret_cast<const V *>(tab + (size_t)row + lo);
     };
 #pragma unroll
     for (int u = 0; u < U; u++) {

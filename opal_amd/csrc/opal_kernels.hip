@@ -104,7 +104,7 @@ __global__ __launch_bounds__(BLOCK) void emit_names_kernel(Batch B, Geom G, cons
     }
 }
 
-template <int VEC, int NV, int U>
+template <int VEC, int NV, int U, bool NT>
 __global__ __launch_bounds__(BLOCK) void predict_kernel(Batch B, Geom G, const float *__restrict__ tab, uint32_t mask, int K,
                                                          int add_constant, uint32_t const_idx, int clip, float min_label,
                                                          float max_label, int32_t *__restrict__ out_class,
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(BLOCK) void predict_kernel(Batch B, Geom G, const f
                 if (lane < HB_PAD) hb[cnt + lane] = const_idx;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                stream_rows<VEC, NV, U>(tab, hb, cnt, Ku, mask, loff, acc);
+                stream_rows<VEC, NV, U, false, NT>(tab, hb, cnt, Ku, mask, loff, acc);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             });
@@ -272,16 +272,20 @@ __global__ void mirror_head_kernel(float *w, uint64_t n_slots, uint32_t pad)
 // ------------------------------------------------------------------------------------------ launch helpers
 struct Variant {
     int vec, nv, u;
-    const void *fn;
+    const void *fn;      // default cache policy: tables that fit the caches
+    const void *fn_nt;   // non-temporal row loads: tables far larger than the caches
     const char *name;
 };
 
-#define OPAL_V(VEC, NV, U) {VEC, NV, U, (const void *)&predict_kernel<VEC, NV, U>, "predict_kernel<VEC=" #VEC ",NV=" #NV ",U=" #U ">"}
+#define OPAL_V(VEC, NV, U) {VEC, NV, U, (const void *)&predict_kernel<VEC, NV, U, false>, (const void *)&predict_kernel<VEC, NV, U, true>, \
+                           "predict_kernel<VEC=" #VEC ",NV=" #NV ",U=" #U ">"}
 const Variant kVariants[] = {
     OPAL_V(1, 1, 8), OPAL_V(1, 2, 8), OPAL_V(1, 3, 4), OPAL_V(1, 4, 4), OPAL_V(1, 5, 2), OPAL_V(1, 6, 2), OPAL_V(1, 7, 2), OPAL_V(1, 8, 2),
     OPAL_V(2, 1, 8), OPAL_V(2, 2, 8), OPAL_V(2, 3, 4), OPAL_V(2, 4, 4), OPAL_V(2, 5, 2), OPAL_V(2, 6, 2), OPAL_V(2, 7, 2), OPAL_V(2, 8, 2),
     OPAL_V(4, 1, 8), OPAL_V(4, 2, 8), OPAL_V(4, 3, 4), OPAL_V(4, 4, 4), OPAL_V(4, 5, 2), OPAL_V(4, 6, 2), OPAL_V(4, 7, 2), OPAL_V(4, 8, 2),
 };
+
+constexpr uint64_t NT_TABLE_BYTES = 4ull << 30;   // tables from this size on are streamed with non-temporal loads
 
 const Variant &pick_variant(int K)
 {
@@ -547,14 +551,18 @@ extern "C" int opal_predict(opal_ctx *ctx, const uint8_t *d_reads, uint64_t read
     const uint32_t mask = ctx->bits == 32 ? 0xffffffffu : ((1u << ctx->bits) - 1u);
     const uint32_t const_idx = OPAL_VW_CONSTANT & mask;
     const Variant &v = pick_variant(ctx->K);
+    // cache policy of the row loads by table size (see nt_load); OPAL_PREDICT_NT=0/1 overrides it for experiments
+    bool nt = ctx->n_slots * sizeof(float) >= NT_TABLE_BYTES;
+    if (const char *e = getenv("OPAL_PREDICT_NT")) nt = atoi(e) != 0;
+    const void *fn = nt ? v.fn_nt : v.fn;
     int grid = 1;
-    rc = grid_for(ctx, v.fn, n, &grid);
+    rc = grid_for(ctx, fn, n, &grid);
     if (rc) return rc;
     const float *tab = ctx->d_w;
     int K = ctx->K, addc = ctx->add_constant, clip = ctx->clip;
     float minl = ctx->min_label, maxl = ctx->max_label;
     OPAL_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), ctx->stream));
     void *args[] = {&B, &G, &tab, (void *)&mask, &K, &addc, (void *)&const_idx, &clip, &minl, &maxl, &d_out_class, &d_out_scores, &ctx->d_queue};
-    OPAL_HIP_CHECK(ctx, hipLaunchKernel(v.fn, dim3(grid), dim3(BLOCK), args, 0, ctx->stream));
+    OPAL_HIP_CHECK(ctx, hipLaunchKernel(fn, dim3(grid), dim3(BLOCK), args, 0, ctx->stream));
     return OPAL_OK;
 }
