@@ -119,6 +119,26 @@ def test_predict_matches_oracle(amd, eng, oracle, golden_dir, K, bits):
     eng.set_vw_options()
 
 
+@pytest.mark.parametrize("K", [1, 3, 10, 64, 130, 356, 1563, 1564, 2050])
+def test_streaming_load_variants_match_oracle(amd, eng, oracle, golden_dir, K, monkeypatch):
+    """Tables of 4 GiB and more are scored by the kernel variants with non-temporal row loads; here they are forced
+    onto a small table (OPAL_PREDICT_NT=1) so that every (VEC, NV) variant is compared with the oracle bit for bit."""
+    rng = np.random.default_rng(K)
+    bits = 18
+    pos = _patterns(amd, golden_dir, "patterns_k64_t16_m1_s7.txt", 64)
+    eng.set_patterns(pos, 64)
+    seqs = _rand_seqs(rng, 50, 200) + [b"", b"ACGT" * 10, bytes(rng.choice(ACGT, size=900))]
+    w = (rng.standard_normal(1 << bits) * 0.05).astype(np.float32)
+    eng.load_weights(w, K, bits)
+    eng.set_vw_options()
+    batch = eng.upload(amd.PackedReads.from_sequences(seqs))
+    ocls, osc, _ = oracle.predict(seqs, 64, pos, True, w, K, bits)
+    for nt in ("1", "0"):
+        monkeypatch.setenv("OPAL_PREDICT_NT", nt)
+        cls, sc = eng.predict(batch, True, want_scores=True)
+        assert np.array_equal(sc.cpu().numpy(), osc) and np.array_equal(cls.cpu().numpy(), ocls), (K, nt)
+
+
 @pytest.mark.parametrize("pattern,k", [("patterns_k64_t16_m4_s7.txt", 64), ("patterns_k64_t16_m8_s7.txt", 64),
                                        ("patterns_k32_t8_m2_s11.txt", 32), ("patterns_hand_k16_t4_p11.txt", 16),
                                        (None, 20)])
