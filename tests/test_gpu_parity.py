@@ -439,14 +439,17 @@ def test_full_size_configs_properties(amd, oracle, golden_dir):
 def test_randomised_geometries_against_oracle(amd, eng, oracle):
     """Seeded fuzz over pattern geometry (k, t, P), fragment lengths (around every tile/buffer boundary), packed/raw
     storage, views at every base phase, K, bits and VW switches: emit and predict must equal the oracle every time."""
-    rng = np.random.default_rng(20240611)
+    # OPAL_FUZZ_SEED / OPAL_FUZZ_TRIALS: longer campaigns with other seeds (run by hand on the GPU box)
+    rng = np.random.default_rng(int(os.environ.get("OPAL_FUZZ_SEED", "20240611")))
     alphabets = [ACGT, np.frombuffer(b"ACGTacgtNn", dtype=np.uint8), np.frombuffer(b"0123456789", dtype=np.uint8)]
-    for trial in range(70):
+    for trial in range(int(os.environ.get("OPAL_FUZZ_TRIALS", "70"))):
         t = int(rng.choice([1, 2, 3, 4, 5, 8, 12, 16, 16, 16, 32, 64]))
         mult = int(rng.integers(1, max(2, min(8, 256 // t) + 1)))
         k = t * mult
         P = int(rng.choice([1, 2, 2, 3, 5, 9, 10, 11, 17, 64]))
         pos = np.stack([np.sort(rng.choice(k, size=t, replace=False)) for _ in range(P)]).astype(np.int32)
+        if rng.random() < 0.3:                                   # Opal's files start with a run of consecutive positions
+            pos[0] = np.arange(t) + int(rng.integers(0, k - t + 1))
         eng.set_patterns(pos, k)
         lens = [int(x) for x in rng.choice([0, 1, k - 1, k, k + 1, k + 63, k + 64, k + 65, 200, 255, 256, 257, 511, 512, 513,
                                             700, 1536 // max(P, 1) + k, 2000], size=12)]
@@ -525,8 +528,8 @@ def test_emit_never_writes_past_out_cap(amd, eng, oracle, golden_dir):
 
 
 def test_randomised_predict_switches_against_oracle(amd, eng, oracle):
-    rng = np.random.default_rng(77001)
-    for trial in range(40):
+    rng = np.random.default_rng(int(os.environ.get("OPAL_FUZZ_SEED", "77001")))
+    for trial in range(int(os.environ.get("OPAL_FUZZ_TRIALS", "40"))):
         t = int(rng.choice([4, 8, 16, 16, 32]))
         k = t * int(rng.integers(1, 5))
         P = int(rng.choice([1, 2, 3, 5, 9, 12]))
