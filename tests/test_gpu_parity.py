@@ -332,9 +332,9 @@ def test_gpu_fasta_ingest_matches_reference_reader(amd, eng, oracle, golden_dir)
         _check_ingest(amd, eng, oracle, c["fasta"].encode("latin-1"))
     for txt, _ in _load(golden_dir, "primitives.json")["fasta_reader"]:
         _check_ingest(amd, eng, oracle, txt.encode("latin-1"))
-    rng = np.random.default_rng(123)
+    rng = np.random.default_rng(int(os.environ.get("OPAL_FUZZ_SEED", "123")))
     pieces = [b"ACGT", b"acgtn", b"N", b"\n", b"\r\n", b"\r", b">", b">name x\n", b"+", b"+\n", b"\n+\n", b"\n>h\n", b" ", b"@r\n"]
-    for trial in range(60):
+    for trial in range(int(os.environ.get("OPAL_FUZZ_TRIALS", "60"))):
         k = int(rng.integers(1, 60))
         txt = b"".join(pieces[int(i)] * int(rng.integers(1, 4)) for i in rng.integers(0, len(pieces), size=k))
         _check_ingest(amd, eng, oracle, txt)
