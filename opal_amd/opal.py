@@ -319,8 +319,44 @@ def train(ref_dir, model_dir, args, engine=None):
     return 0
 
 
+def _next_header(text, start):
+    """Smallest i >= start where a header line begins ('>' right after a line terminator; a lone \\r ends a line too,
+    as in the reference's open(path, 'r')), or len(text) when there is none."""
+    size, window = len(text), 1 << 24
+    i0 = max(start, 1)
+    while i0 < size:
+        w = np.asarray(text[i0 - 1:min(size, i0 + window)])
+        hit = np.flatnonzero((w[1:] == 62) & ((w[:-1] == 10) | (w[:-1] == 13)))
+        if hit.size:
+            return i0 + int(hit[0])
+        i0 += window
+    return size
+
+
+def fasta_pieces(path, chunk_bytes):
+    """The file as uint8 arrays of about chunk_bytes each, cut in front of header lines, so that files larger than host
+    or GPU memory stream through predict the way the reference streams lines into vw (opal.py:458-469).  A header
+    resets the reader's state (fasta_functions.py:24-35), so pieces are independent; every piece but the last gets one
+    extra '>' appended: the reader drops an EMPTY LAST record (fasta_functions.py:20-22), which must only happen at
+    the real end of the file, and that sentinel is exactly such a record."""
+    size = os.path.getsize(path)
+    if size <= chunk_bytes:
+        yield np.fromfile(path, dtype=np.uint8)
+        return
+    text = np.memmap(path, dtype=np.uint8, mode="r")
+    start = 0
+    while start < size:
+        cut = _next_header(text, start + chunk_bytes) if start + chunk_bytes < size else size
+        piece = np.empty(cut - start + (1 if cut < size else 0), dtype=np.uint8)
+        piece[:cut - start] = text[start:cut]
+        if cut < size:
+            piece[-1] = 62
+        yield piece
+        start = cut
+
+
 # ------------------------------------------------------------------ predict (reference opal.py:392-493)
-def predict(model_dir, test_dir, predict_dir, args, engine=None):
+def predict(model_dir, test_dir, predict_dir, args, engine=None, chunk_bytes=None):
     kmer, reverse = args.kmer, args.reverse_complement
     try:
         fasta = glob.glob(test_dir + "/*.fasta")[0]
@@ -352,19 +388,28 @@ def predict(model_dir, test_dir, predict_dir, args, engine=None):
                                 reverse=reverse)
         with open(args.dump_vw_text, "w", encoding="latin-1") as f:
             f.writelines(fasta2skm.main_generator(ns, engine=eng))
-    # the file's bytes go to HBM as they are; records are split and 2-bit packed on the device (opal_ingest_fasta)
-    whole = eng.ingest_fasta(fasta)
-    n_frag = whole.n
-    lo, hi = shard_range(n_frag, rank, world)                # contiguous fragment range per rank
-    if hi > lo:
-        from .engine import DeviceBatch
-        mine = DeviceBatch(whole.data, whole.off[lo:hi], whole.len[lo:hi], hi - lo, whole.nbytes)
-        cls, _ = eng.predict(mine, reverse)
-        local_cls = cls.cpu().numpy()
-    else:
-        local_cls = np.zeros(0, dtype=np.int32)
-    full = gather_in_rank_order(local_cls, dist)
+    # the file's bytes go to HBM as they are, a piece of a few GiB at a time; records are split and 2-bit packed on the
+    # device (opal_ingest_fasta); every rank scores a contiguous range of each piece's fragments
+    from .engine import DeviceBatch
+    if chunk_bytes is None:
+        chunk_bytes = int(os.environ.get("OPAL_PREDICT_CHUNK_BYTES", str(8 << 30)))
+    parts, n_frag = [], 0
+    for piece in fasta_pieces(fasta, chunk_bytes):
+        whole = eng.ingest_fasta(piece)
+        n_frag += whole.n
+        lo, hi = shard_range(whole.n, rank, world)
+        if hi > lo:
+            mine = DeviceBatch(whole.data, whole.off[lo:hi], whole.len[lo:hi], hi - lo, whole.nbytes)
+            cls, _ = eng.predict(mine, reverse)
+            local_cls = cls.cpu().numpy()
+        else:
+            local_cls = np.zeros(0, dtype=np.int32)
+        got = gather_in_rank_order(local_cls, dist)
+        if rank == 0:
+            parts.append(got)
+        del whole, piece
     if rank == 0:
+        full = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int32)
         with open(prefix + "_vwps.log", "w") as log:
             log.write("opal_amd scorer: %d fragments, oaa=%d bits=%d, kernel %s, %d rank(s)\n" % (
                 n_frag, hdr["K"], hdr["bits"], eng.predict_kernel_name(), world))

@@ -291,6 +291,9 @@ def test_cli_predict_two_ranks_equals_one(amd, tmp_path):
             f.write(">r%d\n%s\n" % (i, bytes(ACGT[rng.integers(0, 4, size=int(rng.integers(40, 300)))]).decode()))
     args = argparse.Namespace(kmer=64, reverse_complement=True)
     opal.predict(str(tmp_path / "model"), str(tmp_path / "test"), str(tmp_path / "one"), args)
+    # the same file streamed in header-aligned pieces of ~10 kB (what happens to files beyond a few GiB)
+    opal.predict(str(tmp_path / "model"), str(tmp_path / "test"), str(tmp_path / "pieces"), args, chunk_bytes=10_000)
+    assert (tmp_path / "pieces" / "test.fragments-db.preds.vw").read_bytes() == (tmp_path / "one" / "test.fragments-db.preds.vw").read_bytes()
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]

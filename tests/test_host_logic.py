@@ -199,3 +199,36 @@ def test_write_predictions_equals_reference_style_files(tmp_path):
         opal.write_predictions(np.array([1, 5]), str(dico), str(tmp_path / "q.vw"), str(tmp_path / "q.taxid"))
     opal.write_predictions(np.zeros(0, dtype=np.int32), str(dico), str(tmp_path / "e.vw"), str(tmp_path / "e.taxid"))
     assert (tmp_path / "e.vw").read_bytes() == b"" and (tmp_path / "e.taxid").read_bytes() == b""
+
+
+def test_fasta_pieces_preserve_the_reference_readers_records(tmp_path, oracle):
+    """predict streams big files in pieces cut in front of header lines (opal.fasta_pieces).  Reading every piece with
+    the reference reader's semantics and concatenating the records must give exactly the records of the whole file,
+    for every chunk size: CRLF / lone-CR line ends, '+' quality blocks, empty records (mid-file: kept; at the end of
+    the file: dropped), text before the first header, a file without any header."""
+    from opal_amd import opal
+    rng = np.random.default_rng(5)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    parts = [b"junk before the first header\nACGT\n"]
+    for i in range(400):
+        L = int(rng.integers(0, 300)) if i % 9 else 0                      # every 9th record is empty
+        body = bytes(rng.choice(acgt, size=L))
+        nl = (b"\n", b"\r\n", b"\r")[i % 3]
+        width = int(rng.integers(10, 80))
+        parts.append(b">rec%d x" % i + nl + nl.join(body[j:j + width] for j in range(0, L, width)) + (nl if L else b""))
+        if i % 7 == 0:
+            parts.append(b"+" + nl + b">" * 0 + b"I" * L + nl)
+    texts = [b"".join(parts), b"".join(parts) + b">empty_last\n", b"".join(parts[1:]) + b">e1\n>e2\n", b"ACGT\nACGT\n" * 500,
+             b">only\nACGT", b""]
+    for ti, text in enumerate(texts):
+        path = tmp_path / ("t%d.fasta" % ti)
+        path.write_bytes(text)
+        want = oracle.fasta_read(text)
+        for chunk in (1, 7, 64, 1000, 5000, len(text) + 1):
+            got, n_pieces = [], 0
+            for piece in opal.fasta_pieces(str(path), chunk):
+                got += oracle.fasta_read(piece.tobytes())
+                n_pieces += 1
+            assert [s for _, s in got] == [s for _, s in want], (ti, chunk)
+            if 0 < chunk < len(text) // 4 and b">" in text[1:]:
+                assert n_pieces > 1
