@@ -355,6 +355,31 @@ def fasta_pieces(path, chunk_bytes):
         start = cut
 
 
+def _prefetched(gen, depth=1):
+    """Runs a generator in a background thread, `depth` items ahead: the next piece is read from disk while the GPU
+    scores the current one."""
+    import queue
+    import threading
+    q, done = queue.Queue(maxsize=depth), object()
+
+    def work():
+        try:
+            for item in gen:
+                q.put(item)
+            q.put(done)
+        except BaseException as e:      # hand the error to the consumer
+            q.put(e)
+
+    threading.Thread(target=work, daemon=True).start()
+    while True:
+        item = q.get()
+        if item is done:
+            return
+        if isinstance(item, BaseException):
+            raise item
+        yield item
+
+
 # ------------------------------------------------------------------ predict (reference opal.py:392-493)
 def predict(model_dir, test_dir, predict_dir, args, engine=None, chunk_bytes=None):
     kmer, reverse = args.kmer, args.reverse_complement
@@ -394,7 +419,7 @@ def predict(model_dir, test_dir, predict_dir, args, engine=None, chunk_bytes=Non
     if chunk_bytes is None:
         chunk_bytes = int(os.environ.get("OPAL_PREDICT_CHUNK_BYTES", str(8 << 30)))
     parts, n_frag = [], 0
-    for piece in fasta_pieces(fasta, chunk_bytes):
+    for piece in _prefetched(fasta_pieces(fasta, chunk_bytes)):
         whole = eng.ingest_fasta(piece)
         n_frag += whole.n
         lo, hi = shard_range(whole.n, rank, world)
