@@ -157,11 +157,14 @@ int opal_load_weights_sparse(opal_ctx *ctx, const uint32_t *idx, const float *va
 
 /* GPU-side FASTA ingest.  Replaces fasta_functions.fasta_reader over open(path,'r')
  * (util/fasta_functions.py:9-43, universal newlines, '+' mutes up to the next '>', text before the first '>' is
- * dropped, an empty last record is dropped) followed by opal_pack_reads, for a whole file whose bytes are already
- * in HBM: d_text[nbytes] -> fragment batch (d_reads_out, d_frag_off, d_frag_len) in record order.
- * d_reads_out needs room for reads_cap >= nbytes bytes, d_frag_off/d_frag_len for max_records entries
- * (max_records >= number of '>' in the text, or 1).  Record names are not produced.  Synchronises the stream and
- * returns the record count and the bytes written through the two host pointers.                              */
+ * dropped, an empty last record is dropped) followed by packing, for a whole file whose bytes are already in HBM:
+ * d_text[nbytes] -> fragment batch (d_reads_out, d_frag_off, d_frag_len), one fragment per record in record order.
+ * All sequence bytes of the file go into ONE 2-bit stream at the start of d_reads_out; a record made of upper-case
+ * ACGT is a view into it (d_frag_off in bases, not byte-aligned), any other record is stored as raw bytes behind the
+ * stream (in no particular order).  d_reads_out: 4-byte aligned, reads_cap >= nbytes + nbytes/4 + 64 always suffices
+ * (OPAL_ERANGE if it is too small); d_frag_off/d_frag_len: max_records entries (max_records >= number of '>' in the
+ * text, or 1).  Record names are not produced.  Synchronises the stream and returns the record count and the bytes
+ * of d_reads_out in use through the two host pointers.                                                        */
 int opal_ingest_fasta(opal_ctx *ctx, const uint8_t *d_text, uint64_t nbytes, uint8_t *d_reads_out, uint64_t reads_cap,
                       uint64_t *d_frag_off, uint32_t *d_frag_len, uint64_t max_records, uint64_t *n_records_out,
                       uint64_t *reads_bytes_out);

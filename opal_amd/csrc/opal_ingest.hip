@@ -6,430 +6,479 @@
 // no '>' at all: then it is one unnamed record); a record with an empty sequence is kept mid-file and dropped at
 // end of file.  Record names are not produced (the predict path never uses them).
 //
-// Everything is a prefix scan over bytes with a small associative state:
-//   state(i) = (# header lines started at or before i, last '>'/'+' event, type of the line byte i belongs to)
-//   content(i) = byte i is sequence text  ->  its output position is the exclusive sum of content flags,
-// then records are classified (all upper-case ACGT -> 2-bit packed, else raw) by a flat pass over the sequence bytes
-// and written out: one wave per short record, the whole grid per long record (genomes).
+// The reader is a transducer over bytes with a tiny state (kind of the current line, last '>'/'+' event), so the
+// number of sequence bytes in a stretch of text is an affine function of the state it is entered with.  A stretch
+// is summarised as (headers, last event, last line kind, cA, cB, cC): cA = bytes on the line the stretch starts in
+// (sequence iff that line is a data line of an unmuted record), cB = bytes on its own data lines before its first
+// event (sequence iff the record it continues is unmuted), cC = bytes that are sequence whatever came before.
+// Summaries compose associatively, which gives two passes over the text:
+//   1. ing_summary_kernel   one summary per 16 KiB tile (text read once)
+//   2. ing_scan_kernel      one block scans the tile summaries into the state and sequence position each tile starts at
+//   3. ing_pack_kernel      text read again: every sequence byte now knows its position in the concatenated sequence;
+//                           its 2-bit code goes straight into ONE packed stream of all sequence bytes (LDS-staged,
+//                           whole dwords stored), headers record where their sequence starts, bytes outside ACGT
+//                           flag their record as raw
+//   4. ing_records_kernel   per record: length, offset (packed fragments are addressed in BASES, so a record is a
+//                           view into the stream and needs no alignment), space for raw records behind the stream
+//   5. ing_pack_kernel<RAW> only when some record is raw: third pass that copies the bytes of those records
+// No intermediate copy of the sequence exists; one host synchronisation returns the counts.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <string>
+#include <type_traits>
 
 #include "opal_device.h"
 #include "opal_internal.h"
 
 namespace {
 
-constexpr int ING_ITEMS = 16;                  // bytes per thread
-constexpr int ING_TILE = BLOCK * ING_ITEMS;    // bytes per block
+constexpr int CPT = 4;                               // 16-byte chunks per thread (contiguous)
+constexpr int ING_THREAD_BYTES = 16 * CPT;
+constexpr int ING_TILE = BLOCK * ING_THREAD_BYTES;   // bytes per block
+constexpr int ING_LDS_WORDS = ING_TILE / 16 + 2;     // 2-bit codes of one tile, congruent with the output dwords
+constexpr uint32_t EVEN = 0x55555555u;               // per-byte flags of a chunk live in the even bits: byte j <-> bit 2j
 
-struct St {
-    uint64_t h;    // header-line starts seen
-    uint32_t ev;   // last event: 0 none, 1 '>', 2 '+'
-    uint32_t lt;   // type of the current line: 0 unknown (no line start seen), 1 '>', 2 '+', 3 data
-};
-__device__ __forceinline__ St st_combine(const St &a, const St &b)
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): chunk indices stay compile-time constants, so the
+// per-chunk arrays live in registers (a loop the compiler leaves rolled would move them to scratch or LDS)
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
 {
-    St r;
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+// ---- summaries ------------------------------------------------------------------------------------------------
+// kind: 0 = no line start seen, 1 = header or '+' line, 3 = data line;  ev: 0 = no event seen, 1 = '>', 2 = '+'
+struct Sum { uint32_t h, ev, kind, cA, cB, cC; };
+__device__ __forceinline__ Sum sum_identity() { return Sum{0, 0, 0, 0, 0, 0}; }
+__device__ __forceinline__ Sum sum_combine(const Sum &a, const Sum &b)   // a, then b
+{
+    Sum r;
     r.h = a.h + b.h;
     r.ev = b.ev ? b.ev : a.ev;
-    r.lt = b.lt ? b.lt : a.lt;
+    r.kind = b.kind ? b.kind : a.kind;
+    // b.cA lies on the line a ends in: unknown to a (-> cA), one of a's data lines (-> like cB of a), or not sequence
+    const uint32_t u = b.cB + (a.kind == 3u ? b.cA : 0u);
+    r.cA = a.cA + (a.kind == 0u ? b.cA : 0u);
+    r.cB = a.cB + (a.ev == 0u ? u : 0u);
+    r.cC = a.cC + b.cC + (a.ev == 1u ? u : 0u);
     return r;
 }
-__device__ __forceinline__ St st_shfl_up(const St &v, int d)
+__device__ __forceinline__ Sum sum_shfl_up(const Sum &v, int d)
 {
-    St r;
-    r.h = __shfl_up(v.h, d, WAVE);
-    r.ev = __shfl_up(v.ev, d, WAVE);
-    r.lt = __shfl_up(v.lt, d, WAVE);
+    Sum r;
+    const uint32_t st = (uint32_t)__shfl_up((int)(v.ev | (v.kind << 2)), d, WAVE);
+    r.h = (uint32_t)__shfl_up((int)v.h, d, WAVE);
+    r.ev = st & 3u;
+    r.kind = st >> 2;
+    r.cA = (uint32_t)__shfl_up((int)v.cA, d, WAVE);
+    r.cB = (uint32_t)__shfl_up((int)v.cB, d, WAVE);
+    r.cC = (uint32_t)__shfl_up((int)v.cC, d, WAVE);
     return r;
 }
-__device__ __forceinline__ bool is_term(uint32_t c) { return c == '\n' || c == '\r'; }
 
-// The contribution of byte i: a line start sets the line type (and an event for '>' / '+').
-__device__ __forceinline__ St st_of_byte(uint32_t c, uint32_t prev, bool first)
+// the reader's concrete state in front of a stretch: headers seen, sequence bytes so far, last event, line kind
+struct Pre { uint64_t h, cnt; uint32_t ev, kind; };
+__device__ __forceinline__ Pre pre_apply(const Pre &p, const Sum &s)
 {
-    St s{0, 0, 0};
-    const bool line_start = first || prev == '\n' || (prev == '\r' && c != '\n');
-    if (line_start) {
-        if (c == '>') { s.h = 1; s.ev = 1; s.lt = 1; }
-        else if (c == '+') { s.ev = 2; s.lt = 2; }
-        else s.lt = 3;
+    Pre r;
+    const bool open = p.ev != 2u;
+    r.cnt = p.cnt + ((open && p.kind == 3u) ? s.cA : 0u) + (open ? s.cB : 0u) + s.cC;
+    r.h = p.h + s.h;
+    r.ev = s.ev ? s.ev : p.ev;
+    r.kind = s.kind ? s.kind : p.kind;
+    return r;
+}
+
+// Block-wide scan of per-thread summaries (256 threads): returns this thread's exclusive prefix, the block total
+// through `total`.  Contains two __syncthreads.
+__device__ __forceinline__ Sum block_excl_scan_sum(const Sum &v, Sum *s_w, Sum &total)
+{
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    Sum incl = v;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const Sum o = sum_shfl_up(incl, d);
+        if (lane >= d) incl = sum_combine(o, incl);
     }
+    if (lane == WAVE - 1) s_w[wv] = incl;
+    __syncthreads();
+    Sum base = sum_identity();
+    total = sum_identity();
+#pragma unroll
+    for (int w = 0; w < WPB; w++) {
+        if (w < wv) base = sum_combine(base, s_w[w]);
+        total = sum_combine(total, s_w[w]);
+    }
+    Sum excl = sum_shfl_up(incl, 1);
+    if (lane == 0) excl = sum_identity();
+    __syncthreads();
+    return sum_combine(base, excl);
+}
+
+// ---- 16 bytes at a time ------------------------------------------------------------------------------------------
+// 0x80 in every byte of x that equals the byte replicated in pat (exact for all byte values)
+__device__ __forceinline__ uint32_t eq_flags(uint32_t x, uint32_t pat)
+{
+    const uint32_t t = x ^ pat;
+    return ~((((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) | 0x7f7f7f7fu);
+}
+// bits 8b and 8b+1 of f (b = 0..3) -> bits 2b and 2b+1
+__device__ __forceinline__ uint32_t squeeze2(uint32_t f) { return (f | (f >> 6) | (f >> 12) | (f >> 18)) & 0xffu; }
+
+__device__ __forceinline__ uint32_t chunk_byte(const uint32_t (&x)[4], uint32_t j)
+{
+    // the four dwords as values first: a select between array elements becomes a select between addresses, which
+    // sends the whole array to scratch / LDS
+    const uint32_t x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
+    const uint32_t lo = j < 4u ? x0 : x1, hi = j < 12u ? x2 : x3;
+    const uint32_t w = j < 8u ? lo : hi;
+    return (w >> ((j & 3u) * 8u)) & 0xffu;
+}
+
+// Terminator flags of a chunk: bit 2j = byte j is '\r', bit 2j+1 = byte j is '\n'
+__device__ __forceinline__ uint32_t term_fields(const uint32_t (&x)[4])
+{
+    uint32_t I = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t m = eq_flags(x[d], 0x0a0a0a0au) | (eq_flags(x[d], 0x0d0d0d0du) >> 1);
+        I |= squeeze2(m >> 6) << (8 * d);
+    }
+    return I;
+}
+
+// The thread's bytes: CPT chunks of 16, bytes past the end of the text read as '\n'; valid[c] = even-bit mask of the
+// bytes of chunk c that exist; prev = the byte in front of the thread's first byte (0 at the start of the text).
+__device__ __forceinline__ void load_chunks(const uint8_t *__restrict__ text, uint64_t n, uint64_t base, uint32_t (&x)[CPT][4],
+                                            uint32_t (&valid)[CPT], uint32_t &prev)
+{
+    prev = (base > 0 && base <= n) ? text[base - 1] : 0u;
+    if (base + ING_THREAD_BYTES <= n && (reinterpret_cast<uintptr_t>(text) & 15u) == 0) {
+        static_for<CPT>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            const uint4 v = *reinterpret_cast<const uint4 *>(text + base + 16 * c);
+            x[c][0] = v.x; x[c][1] = v.y; x[c][2] = v.z; x[c][3] = v.w;
+            valid[c] = EVEN;
+        });
+    } else {
+        static_for<CPT>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            uint32_t nv = 0;
+            static_for<4>([&](auto di) {
+                constexpr int d = decltype(di)::value;
+                uint32_t w = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const uint64_t p = base + 16 * c + 4 * d + b;
+                    const uint32_t ch = p < n ? (uint32_t)text[p] : (uint32_t)'\n';
+                    nv += p < n ? 1u : 0u;
+                    w |= ch << (8 * b);
+                }
+                x[c][d] = w;
+            });
+            valid[c] = nv >= 16u ? EVEN : (((1u << (2u * nv)) - 1u) & EVEN);
+        });
+    }
+}
+
+// Line starts and non-terminator bytes of one chunk (even-bit masks).  nl_in / cr_in: the byte in front of the chunk
+// is '\n' / '\r'; on return they describe the chunk's last byte.
+__device__ __forceinline__ void chunk_lines(const uint32_t (&x)[4], uint32_t valid, bool first, uint32_t &nl_in, uint32_t &cr_in,
+                                            uint32_t &LS, uint32_t &NT)
+{
+    const uint32_t I = term_fields(x);
+    const uint32_t nlo = I & ~EVEN, cre = I & EVEN;
+    // a byte starts a line after '\n', or after a '\r' that is not followed by '\n' (universal newlines)
+    LS = ((((nlo << 1) | nl_in) | (((cre << 2) | cr_in) & ~(nlo >> 1))) & EVEN) | (first ? 1u : 0u);
+    LS &= valid;
+    NT = ~((nlo >> 1) | cre) & valid;
+    nl_in = I >> 31;
+    cr_in = (I >> 30) & 1u;
+}
+
+// Symbolic walk of one chunk: which bytes are sequence under which condition on the state the THREAD is entered with.
+struct Walk { uint32_t kind, ev, h; };                // running state of the thread (0 = still the incoming one)
+struct Masks { uint32_t mA, mB, mC, HD; };           // cA / cB / cC bytes and the '>' line starts of the chunk
+__device__ __forceinline__ Masks walk_chunk(const uint32_t (&x)[4], uint32_t LS, uint32_t NT, Walk &w)
+{
+    Masks m{0, 0, 0, 0};
+    const uint32_t pre = NT & (LS ? ((LS & (0u - LS)) - 1u) : 0xffffffffu);   // bytes of the line the chunk starts in
+    if (w.kind == 0u) m.mA = pre;
+    else if (w.kind == 3u) {
+        if (w.ev == 0u) m.mB = pre;
+        else if (w.ev == 1u) m.mC = pre;
+    }
+    uint32_t rem = LS;
+    while (rem) {
+        const uint32_t bit = rem & (0u - rem);
+        rem ^= bit;
+        const uint32_t next = rem & (0u - rem);             // 0 when this is the chunk's last line start
+        const uint32_t c = chunk_byte(x, (uint32_t)__builtin_ctz(bit) >> 1);
+        if (c == '>') { w.h++; w.ev = 1u; w.kind = 1u; m.HD |= bit; }
+        else if (c == '+') { w.ev = 2u; w.kind = 1u; }
+        else {
+            w.kind = 3u;
+            const uint32_t s = NT & (next - 1u) & ~(bit - 1u);   // bytes from this line start up to the next one
+            if (w.ev == 0u) m.mB |= s;
+            else if (w.ev == 1u) m.mC |= s;
+        }
+    }
+    return m;
+}
+
+// Everything the two text passes share: loads the thread's bytes, walks them, returns the thread's summary.
+__device__ __forceinline__ Sum analyse_thread(const uint8_t *__restrict__ text, uint64_t n, uint64_t base, uint32_t (&x)[CPT][4],
+                                              Masks (&m)[CPT])
+{
+    uint32_t valid[CPT], prev;
+    load_chunks(text, n, base, x, valid, prev);
+    uint32_t nl_in = prev == '\n' ? 1u : 0u, cr_in = prev == '\r' ? 1u : 0u;
+    Walk w{0, 0, 0};
+    Sum s = sum_identity();
+    static_for<CPT>([&](auto ci) {
+        constexpr int c = decltype(ci)::value;
+        uint32_t LS, NT;
+        chunk_lines(x[c], valid[c], base == 0 && c == 0, nl_in, cr_in, LS, NT);
+        m[c] = walk_chunk(x[c], LS, NT, w);
+        s.cA += (uint32_t)__builtin_popcount(m[c].mA);
+        s.cB += (uint32_t)__builtin_popcount(m[c].mB);
+        s.cC += (uint32_t)__builtin_popcount(m[c].mC);
+    });
+    s.h = w.h; s.ev = w.ev; s.kind = w.kind;
     return s;
 }
 
-// Block-wide exclusive scan of per-thread aggregates (256 threads); returns this thread's exclusive prefix and
-// the block total through `total`.
-__device__ __forceinline__ St block_excl_scan_st(St v, St *s_w, St &total)
+// ---- pass 1: one summary per tile --------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void ing_summary_kernel(const uint8_t *__restrict__ text, uint64_t n, Sum *__restrict__ tile_sum)
 {
+    __shared__ Sum s_w[WPB];
+    const uint64_t base = (uint64_t)blockIdx.x * ING_TILE + (uint64_t)threadIdx.x * ING_THREAD_BYTES;
+    uint32_t x[CPT][4];
+    Masks m[CPT];
+    Sum v = analyse_thread(text, n, base, x, m);
+    // ordered reduction (the combine is not commutative): lane i takes in lanes i+d .. after its own
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
-    St incl = v;
 #pragma unroll
     for (int d = 1; d < WAVE; d <<= 1) {
-        const St o = st_shfl_up(incl, d);
-        if (lane >= d) incl = st_combine(o, incl);
+        Sum o;
+        const uint32_t st = (uint32_t)__shfl_down((int)(v.ev | (v.kind << 2)), d, WAVE);
+        o.h = (uint32_t)__shfl_down((int)v.h, d, WAVE);
+        o.ev = st & 3u; o.kind = st >> 2;
+        o.cA = (uint32_t)__shfl_down((int)v.cA, d, WAVE);
+        o.cB = (uint32_t)__shfl_down((int)v.cB, d, WAVE);
+        o.cC = (uint32_t)__shfl_down((int)v.cC, d, WAVE);
+        if (lane + d < WAVE) v = sum_combine(v, o);
     }
-    if (lane == WAVE - 1) s_w[wv] = incl;
+    if (lane == 0) s_w[wv] = v;
     __syncthreads();
-    St base{0, 0, 0};
-    total = St{0, 0, 0};
+    if (threadIdx.x == 0) {
+        Sum t = s_w[0];
 #pragma unroll
-    for (int w = 0; w < WPB; w++) {
-        if (w < wv) base = st_combine(base, s_w[w]);
-        total = st_combine(total, s_w[w]);
-    }
-    St excl_in_wave = st_shfl_up(incl, 1);
-    if (lane == 0) excl_in_wave = St{0, 0, 0};
-    __syncthreads();
-    return st_combine(base, excl_in_wave);
-}
-
-__device__ __forceinline__ uint64_t block_excl_scan_u64(uint64_t v, uint64_t *s_w, uint64_t &total)
-{
-    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
-    uint64_t incl = v;
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        const uint64_t o = __shfl_up(incl, d, WAVE);
-        if (lane >= d) incl += o;
-    }
-    if (lane == WAVE - 1) s_w[wv] = incl;
-    __syncthreads();
-    uint64_t base = 0;
-    total = 0;
-#pragma unroll
-    for (int w = 0; w < WPB; w++) {
-        if (w < wv) base += s_w[w];
-        total += s_w[w];
-    }
-    __syncthreads();
-    return base + incl - v;
-}
-
-// the ING_ITEMS bytes of one thread: one 16-byte load when the text pointer allows it (bytes past the end read as '\n')
-__device__ __forceinline__ void load_items(const uint8_t *__restrict__ text, uint64_t n, uint64_t base, uint8_t (&c)[ING_ITEMS])
-{
-    static_assert(ING_ITEMS == 16, "one uint4 per thread");
-    if (base + ING_ITEMS <= n && (reinterpret_cast<uintptr_t>(text) & 15u) == 0) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(text + base);
-        __builtin_memcpy(c, &v, ING_ITEMS);
-    } else {
-#pragma unroll
-        for (int i = 0; i < ING_ITEMS; i++) c[i] = base + i < n ? text[base + i] : (uint8_t)'\n';
+        for (int w = 1; w < WPB; w++) t = sum_combine(t, s_w[w]);
+        tile_sum[blockIdx.x] = t;
     }
 }
 
-// pass 1: per-tile aggregate state
-__global__ __launch_bounds__(BLOCK) void ing_tile_state_kernel(const uint8_t *__restrict__ text, uint64_t n, St *__restrict__ tile_st)
-{
-    __shared__ St s_w[WPB];
-    const uint64_t base = (uint64_t)blockIdx.x * ING_TILE + (uint64_t)threadIdx.x * ING_ITEMS;
-    St agg{0, 0, 0};
-    uint32_t prev = (base > 0 && base <= n) ? text[base - 1] : 0;
-    uint8_t c[ING_ITEMS];
-    load_items(text, n, base, c);
-#pragma unroll
-    for (int i = 0; i < ING_ITEMS; i++) {
-        const uint64_t p = base + i;
-        if (p < n) {
-            agg = st_combine(agg, st_of_byte(c[i], prev, p == 0));
-            prev = c[i];
-        }
-    }
-    St total;
-    (void)block_excl_scan_st(agg, s_w, total);
-    if (threadIdx.x == 0) tile_st[blockIdx.x] = total;
-}
-
-// pass 2: exclusive scan of the tile aggregates by one block (SC_ITEMS consecutive tiles per thread and round);
-// grand total to *total_out
+// ---- pass 2: the state every tile starts in ----------------------------------------------------------------------
+// fin: [0] headers in the text, [1] sequence bytes T, [2] cursor of the raw area (starts behind the packed stream),
+//      [3] raw records, [4] a record is longer than 2^31-1, [5] the last record is empty (dropped), [6] raw area overflow
+enum { F_H = 0, F_T, F_CURSOR, F_NRAW, F_TOOLONG, F_DROPPED, F_OVERFLOW, F_WORDS = 8 };
 constexpr int SC_ITEMS = 8;
-__global__ __launch_bounds__(BLOCK) void ing_scan_tiles_st_kernel(St *__restrict__ tile_st, uint64_t ntiles, St *__restrict__ total_out)
+__global__ __launch_bounds__(BLOCK) void ing_scan_kernel(const Sum *__restrict__ tile_sum, uint64_t ntiles, Pre *__restrict__ tile_pre,
+                                                          uint64_t *__restrict__ fin)
 {
-    __shared__ St s_w[WPB];
-    __shared__ St s_carry;
-    if (threadIdx.x == 0) s_carry = St{0, 0, 0};
+    __shared__ Sum s_w[WPB];
+    __shared__ Pre s_carry;
+    if (threadIdx.x == 0) s_carry = Pre{0, 0, 0, 0};
     __syncthreads();
-    for (uint64_t b0 = 0; b0 < ntiles; b0 += (uint64_t)BLOCK * SC_ITEMS) {
+    for (uint64_t b0 = 0; b0 < ntiles; b0 += (uint64_t)BLOCK * SC_ITEMS) {   // 2048 tiles = 32 MiB of text: u32 counts hold
         const uint64_t i0 = b0 + (uint64_t)threadIdx.x * SC_ITEMS;
-        St v[SC_ITEMS], agg{0, 0, 0};
+        Sum v[SC_ITEMS], agg = sum_identity();
 #pragma unroll
         for (int j = 0; j < SC_ITEMS; j++) {
-            v[j] = i0 + j < ntiles ? tile_st[i0 + j] : St{0, 0, 0};
-            agg = st_combine(agg, v[j]);
+            v[j] = i0 + j < ntiles ? tile_sum[i0 + j] : sum_identity();
+            agg = sum_combine(agg, v[j]);
         }
-        St total;
-        const St excl = block_excl_scan_st(agg, s_w, total);
-        const St carry = s_carry;
-        St run = st_combine(carry, excl);
+        Sum total;
+        const Sum excl = block_excl_scan_sum(agg, s_w, total);
+        const Pre carry = s_carry;
+        Pre run = pre_apply(carry, excl);
 #pragma unroll
         for (int j = 0; j < SC_ITEMS; j++) {
-            if (i0 + j < ntiles) tile_st[i0 + j] = run;
-            run = st_combine(run, v[j]);
+            if (i0 + j < ntiles) tile_pre[i0 + j] = run;
+            run = pre_apply(run, v[j]);
         }
         __syncthreads();
-        if (threadIdx.x == 0) s_carry = st_combine(carry, total);
+        if (threadIdx.x == 0) s_carry = pre_apply(carry, total);
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total_out = s_carry;
-}
-
-__global__ __launch_bounds__(BLOCK) void ing_scan_tiles_u64_kernel(uint64_t *__restrict__ tile_v, uint64_t ntiles, uint64_t *__restrict__ total_out)
-{
-    __shared__ uint64_t s_w[WPB];
-    __shared__ uint64_t s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    for (uint64_t b0 = 0; b0 < ntiles; b0 += (uint64_t)BLOCK * SC_ITEMS) {
-        const uint64_t i0 = b0 + (uint64_t)threadIdx.x * SC_ITEMS;
-        uint64_t v[SC_ITEMS], agg = 0;
-#pragma unroll
-        for (int j = 0; j < SC_ITEMS; j++) {
-            v[j] = i0 + j < ntiles ? tile_v[i0 + j] : 0ull;
-            agg += v[j];
-        }
-        uint64_t total;
-        const uint64_t excl = block_excl_scan_u64(agg, s_w, total);
-        const uint64_t carry = s_carry;
-        uint64_t run = carry + excl;
-#pragma unroll
-        for (int j = 0; j < SC_ITEMS; j++) {
-            if (i0 + j < ntiles) tile_v[i0 + j] = run;
-            run += v[j];
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) s_carry = carry + total;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *total_out = s_carry;
-}
-
-// passes 3 and 5 share this body.  WRITE=false: count the content bytes of each tile.
-// WRITE=true: compact content bytes to seq[pos] and record where each header's sequence starts.
-template <bool WRITE>
-__global__ __launch_bounds__(BLOCK) void ing_content_kernel(const uint8_t *__restrict__ text, uint64_t n,
-                                                             const St *__restrict__ tile_st, const St *__restrict__ total_st,
-                                                             uint64_t *__restrict__ tile_cnt, uint8_t *__restrict__ seq,
-                                                             uint64_t *__restrict__ seq_start, uint64_t max_records)
-{
-    __shared__ St s_w[WPB];
-    __shared__ uint64_t s_c[WPB];
-    const uint64_t base = (uint64_t)blockIdx.x * ING_TILE + (uint64_t)threadIdx.x * ING_ITEMS;
-    const bool any_header = total_st->h > 0;
-    uint8_t c[ING_ITEMS];
-    St agg{0, 0, 0};
-    uint32_t prev0 = (base > 0 && base <= n) ? text[base - 1] : 0;
-    uint32_t prev = prev0;
-    load_items(text, n, base, c);
-#pragma unroll
-    for (int i = 0; i < ING_ITEMS; i++) {
-        const uint64_t p = base + i;
-        if (p < n) {
-            agg = st_combine(agg, st_of_byte(c[i], prev, p == 0));
-            prev = c[i];
-        }
-    }
-    St total;
-    St run = st_combine(tile_st[blockIdx.x], block_excl_scan_st(agg, s_w, total));
-    // per-byte state + content flags
-    uint32_t flags = 0, hdr = 0;
-    uint64_t hcount[ING_ITEMS];
-    prev = prev0;
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int i = 0; i < ING_ITEMS; i++) {
-        const uint64_t p = base + i;
-        if (p < n) {
-            const St b = st_of_byte(c[i], prev, p == 0);
-            run = st_combine(run, b);
-            prev = c[i];
-            // lt==0 only happens before any line start, i.e. never (byte 0 is a line start)
-            const bool content = !is_term(c[i]) && run.lt == 3 && run.ev != 2 && (run.h > 0 || !any_header);
-            if (content) { flags |= 1u << i; cnt++; }
-            if (b.h) hdr |= 1u << i;
-        }
-        hcount[i] = run.h;
-    }
-    uint64_t tot;
-    const uint64_t excl = block_excl_scan_u64(cnt, s_c, tot);
-    if (!WRITE) {
-        if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
-        return;
-    }
-    uint64_t pos = tile_cnt[blockIdx.x] + excl;
-#pragma unroll
-    for (int i = 0; i < ING_ITEMS; i++) {
-        if (hdr & (1u << i)) {
-            const uint64_t r = hcount[i] - 1;                 // record index of this header
-            if (r < max_records) seq_start[r] = pos;
-        }
-        if (flags & (1u << i)) seq[pos++] = c[i];
+    if (threadIdx.x == 0) {
+        fin[F_H] = s_carry.h;
+        fin[F_T] = s_carry.cnt;
+        fin[F_CURSOR] = (((s_carry.cnt + 3) / 4) + 15) & ~15ull;   // raw records go behind the packed stream
     }
 }
 
-// Classification is flat over the compacted sequence bytes, so one 4 Mbp genome occupies the whole chip just as
-// 4M short reads do: a thread looks at 16 bytes; only a byte outside ACGT (rare) costs a binary search for its
-// record and a store of 1 into that record's flag.
-constexpr int CL_ITEMS = 16;
-__device__ __forceinline__ uint64_t record_of(const uint64_t *__restrict__ seq_start, uint64_t n_rec, uint64_t pos)
+// ---- pass 3 (and 5): sequence bytes to their place ------------------------------------------------------------------
+// removes the 2-bit fields of v whose field in keep (both bits set for a kept field) is clear
+__device__ __forceinline__ uint32_t squeeze_fields(uint32_t v, uint32_t keep)
 {
-    // last r with seq_start[r] <= pos (empty records share a start with their successor: the last one holds the byte)
-    uint64_t lo = 0, hi = n_rec - 1;
-    while (lo < hi) {
-        const uint64_t mid = (lo + hi + 1) >> 1;
-        if (seq_start[mid] <= pos) lo = mid; else hi = mid - 1;
+    v &= keep;
+    while (keep != 0xffffffffu) {
+        const uint32_t b = (uint32_t)__builtin_ctz(~keep);    // lowest hole
+        const uint32_t up = keep >> b;
+        if (!up) break;                                        // nothing kept above it
+        const uint32_t run = (uint32_t)__builtin_ctz(up);
+        const uint32_t low = (1u << b) - 1u;
+        v = (v & low) | ((v >> run) & ~low);
+        keep = (keep & low) | ((keep >> run) & ~low);
     }
-    return lo;
+    return v;
 }
-__global__ __launch_bounds__(BLOCK) void ing_classify_kernel(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ seq_start,
-                                                              uint64_t n_rec, uint64_t total_content, uint32_t *__restrict__ raw_flag)
+
+// RAWCOPY=false: 2-bit codes of all sequence bytes into the packed stream out32 (base p of the concatenated sequence in
+// bits 2*(p&15) of dword p>>4; the stream must be zeroed: tiles meet inside dwords), seq_start[r] for every header,
+// raw_flag[r] for every record that holds a byte outside ACGT.
+// RAWCOPY=true: the bytes of the records flagged raw to out8[frag_off[r] + i].
+template <bool RAWCOPY>
+__global__ __launch_bounds__(BLOCK) void ing_pack_kernel(const uint8_t *__restrict__ text, uint64_t n, const Pre *__restrict__ tile_pre,
+                                                          uint64_t *__restrict__ fin, uint32_t *__restrict__ out32, uint64_t cap_words,
+                                                          uint64_t *__restrict__ seq_start, uint32_t *__restrict__ raw_flag,
+                                                          uint64_t max_records, uint8_t *__restrict__ out8, uint64_t reads_cap,
+                                                          const uint64_t *__restrict__ frag_off)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * BLOCK * CL_ITEMS;
-    for (uint64_t base = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * CL_ITEMS; base < total_content; base += stride) {
-        uint8_t c[CL_ITEMS];
-        if (base + CL_ITEMS <= total_content) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(seq + base);      // seq comes from hipMalloc, base % 16 == 0
-            __builtin_memcpy(c, &v, CL_ITEMS);
+    __shared__ Sum s_w[WPB];
+    __shared__ uint32_t s_bits[RAWCOPY ? 1 : ING_LDS_WORDS];
+    if (!RAWCOPY)
+        for (int i = threadIdx.x; i < ING_LDS_WORDS; i += BLOCK) s_bits[i] = 0;   // ordered by the scan's barriers
+    const uint64_t base = (uint64_t)blockIdx.x * ING_TILE + (uint64_t)threadIdx.x * ING_THREAD_BYTES;
+    uint32_t x[CPT][4];
+    Masks m[CPT];
+    const Sum mine = analyse_thread(text, n, base, x, m);
+    Sum total;
+    const Sum excl = block_excl_scan_sum(mine, s_w, total);
+    const Pre tp = tile_pre[blockIdx.x];
+    const Pre in = pre_apply(tp, excl);
+    const bool open = in.ev != 2u, open_a = open && in.kind == 3u;
+    const uint64_t H = fin[F_H];
+    uint64_t cnt = in.cnt, hrun = in.h;
+    uint32_t lpos = (uint32_t)(tp.cnt & 15u) + (uint32_t)(in.cnt - tp.cnt);
+    static_for<CPT>([&](auto ci) {
+        constexpr int c = decltype(ci)::value;
+        const uint32_t CM = m[c].mC | (open ? m[c].mB : 0u) | (open_a ? m[c].mA : 0u);
+        const uint64_t h_in = hrun;                                   // headers in front of this chunk
+        if (!RAWCOPY) {
+            uint32_t hd = m[c].HD;
+            while (hd) {
+                const uint32_t bit = hd & (0u - hd);
+                hd ^= bit;
+                const uint64_t r = hrun++;
+                if (r < max_records) seq_start[r] = cnt + (uint32_t)__builtin_popcount(CM & (bit - 1u));
+            }
+            uint32_t codes = 0, bad = 0;
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                // A=0x41 C=0x43 G=0x47 T=0x54: (ch >> 1) & 3 gives 0,1,3,2 -> fix the G/T order
+                uint32_t q = (x[c][d] >> 1) & 0x03030303u;
+                q ^= (q >> 1) & 0x01010101u;
+                codes |= squeeze2(q) << (8 * d);
+                const uint32_t diff = x[c][d] ^ __builtin_amdgcn_perm(0u, 0x54474341u, q);        // "ACGT"[code] == byte ?
+                const uint32_t nz = (((diff & 0x7f7f7f7fu) + 0x7f7f7f7fu) | diff) & 0x80808080u;
+                bad |= (squeeze2(nz >> 7) & 0x55u) << (8 * d);
+            }
+            bad &= CM;
+            uint64_t last_r = ~0ull;
+            while (bad) {
+                const uint32_t bit = bad & (0u - bad);
+                bad ^= bit;
+                const uint64_t hh = h_in + (uint32_t)__builtin_popcount(m[c].HD & (bit - 1u));
+                if (hh == 0 && H != 0) continue;                       // text before the first header
+                const uint64_t r = hh ? hh - 1 : 0;
+                if (r == last_r || r >= max_records) continue;
+                last_r = r;
+                if (__atomic_load_n(&raw_flag[r], __ATOMIC_RELAXED) == 0u && atomicExch(&raw_flag[r], 1u) == 0u)
+                    atomicAdd((unsigned long long *)&fin[F_NRAW], 1ull);
+            }
+            const uint32_t nf = (uint32_t)__builtin_popcount(CM);
+            if (nf) {
+                codes = squeeze_fields(codes, CM | (CM << 1));
+                const uint32_t lbit = 2u * lpos, sh = lbit & 31u;
+                atomicOr(&s_bits[lbit >> 5], codes << sh);
+                if (sh && (codes >> (32u - sh))) atomicOr(&s_bits[(lbit >> 5) + 1], codes >> (32u - sh));
+            }
+            lpos += nf;
+            cnt += nf;
         } else {
-#pragma unroll
-            for (int i = 0; i < CL_ITEMS; i++) c[i] = base + i < total_content ? seq[base + i] : (uint8_t)'A';
+            // the chunk's sequence bytes, one record (stretch between headers) at a time
+            uint32_t hd = m[c].HD, from = 0xffffffffu;
+            uint64_t hcur = h_in;
+            while (CM) {
+                const uint32_t nb = hd & (0u - hd);                     // next header in the chunk (0: none)
+                uint32_t seg = CM & from & (nb - 1u);
+                if (seg && (hcur != 0 || H == 0)) {
+                    const uint64_t r = hcur ? hcur - 1 : 0;
+                    if (r < max_records && raw_flag[r]) {
+                        const uint64_t dst0 = frag_off[r] + (cnt - seq_start[r]);
+                        while (seg) {
+                            const uint32_t bit = seg & (0u - seg);
+                            seg ^= bit;
+                            const uint64_t dst = dst0 + (uint32_t)__builtin_popcount(CM & (bit - 1u));
+                            if (dst < reads_cap) out8[dst] = (uint8_t)chunk_byte(x[c], (uint32_t)__builtin_ctz(bit) >> 1);
+                        }
+                    }
+                }
+                if (!nb) break;
+                hd ^= nb;
+                from = ~(nb - 1u);
+                hcur++;
+            }
+            hrun += (uint32_t)__builtin_popcount(m[c].HD);
+            cnt += (uint32_t)__builtin_popcount(CM);
         }
-        uint32_t bad = 0;
-#pragma unroll
-        for (int i = 0; i < CL_ITEMS; i++) {
-            const uint32_t ch = c[i];
-            if (!(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T')) bad |= 1u << i;
-        }
-        while (bad) {
-            const int i = __builtin_ctz(bad);
-            bad &= bad - 1;
-            raw_flag[record_of(seq_start, n_rec, base + i)] = 1u;   // same value from every writer
+    });
+    if (!RAWCOPY) {
+        __syncthreads();
+        const uint64_t tot = pre_apply(tp, total).cnt - tp.cnt;
+        const uint64_t g0 = tp.cnt >> 4;
+        const uint32_t nd = (uint32_t)(((tp.cnt & 15u) + tot + 15u) >> 4);
+        for (uint32_t i = threadIdx.x; i < nd; i += BLOCK) {
+            const uint32_t v = s_bits[i];
+            if (g0 + i >= cap_words) continue;
+            if (i == 0 || i == nd - 1) { if (v) atomicOr(&out32[g0 + i], v); }   // dwords shared with a neighbouring tile
+            else out32[g0 + i] = v;
         }
     }
 }
 
-// per record: length word, output bytes; records longer than LONG_BASES go on the list of ing_pack_long_kernel
-constexpr uint64_t LONG_BASES = 1u << 16;
-constexpr uint32_t LONG_CAP = 1u << 16;
-__global__ __launch_bounds__(BLOCK) void ing_lens_kernel(const uint64_t *__restrict__ seq_start, uint64_t n_rec, uint64_t total_content,
-                                                          const uint32_t *__restrict__ raw_flag, uint32_t *__restrict__ frag_len,
-                                                          uint64_t *__restrict__ rec_bytes, uint64_t *__restrict__ too_long,
-                                                          unsigned int *__restrict__ long_count, uint64_t *__restrict__ long_list)
+// ---- pass 4: records ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void ing_records_kernel(const uint64_t *__restrict__ seq_start, const uint32_t *__restrict__ raw_flag,
+                                                             uint64_t *__restrict__ fin, uint64_t max_records, uint64_t reads_cap,
+                                                             uint64_t *__restrict__ frag_off, uint32_t *__restrict__ frag_len)
 {
+    const uint64_t H = fin[F_H], T = fin[F_T];
+    if (H > max_records) return;                               // reported by the host
+    const uint64_t n_rec = H ? H : (T ? 1 : 0);
     const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
     for (uint64_t r = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; r < n_rec; r += stride) {
         const uint64_t s = seq_start[r];
-        const uint64_t e = (r + 1 < n_rec) ? seq_start[r + 1] : total_content;
+        const uint64_t e = (r + 1 < n_rec) ? seq_start[r + 1] : T;
         const uint64_t len = e - s;
+        if (H && r == n_rec - 1 && len == 0) { fin[F_DROPPED] = 1; continue; }   // fasta_functions.py:20-22
         const bool raw = raw_flag[r] != 0;
-        if (len > 0x7fffffffull) *too_long = 1;           // reported as OPAL_EINVAL by the host; plain store of a constant
+        if (len > 0x7fffffffull) fin[F_TOOLONG] = 1;           // plain stores of a constant
         const uint32_t l31 = len > 0x7fffffffull ? 0x7fffffffu : (uint32_t)len;
         frag_len[r] = l31 | (raw ? OPAL_RAW_FLAG : 0u);
-        rec_bytes[r] = raw ? len : (len + 3) / 4;
-        if (len > LONG_BASES) {
-            const unsigned int at = atomicAdd(long_count, 1u);
-            if (at < LONG_CAP) long_list[at] = r;
+        if (raw) {
+            const uint64_t o = atomicAdd((unsigned long long *)&fin[F_CURSOR], (unsigned long long)len);
+            if (o + len > reads_cap) fin[F_OVERFLOW] = 1;
+            frag_off[r] = o;                                   // raw fragments are addressed in bytes
+        } else {
+            frag_off[r] = s;                                   // packed fragments in bases: a view into the stream
         }
-    }
-}
-
-// exclusive scan over records of rec_bytes (tile = 256*8 records), 3 launches like the offsets scan
-constexpr int RS_ITEMS = 8;
-constexpr int RS_TILE = BLOCK * RS_ITEMS;
-template <bool WRITE>
-__global__ __launch_bounds__(BLOCK) void ing_rec_scan_kernel(const uint64_t *__restrict__ rec_bytes, const uint32_t *__restrict__ frag_len,
-                                                              uint64_t n_rec, uint64_t *__restrict__ tile_v,
-                                                              uint64_t *__restrict__ out_byte_off, uint64_t *__restrict__ frag_off)
-{
-    __shared__ uint64_t s_w[WPB];
-    const uint64_t base = (uint64_t)blockIdx.x * RS_TILE + (uint64_t)threadIdx.x * RS_ITEMS;
-    uint64_t v[RS_ITEMS], sum = 0;
-#pragma unroll
-    for (int i = 0; i < RS_ITEMS; i++) {
-        v[i] = base + i < n_rec ? rec_bytes[base + i] : 0ull;
-        sum += v[i];
-    }
-    uint64_t tot;
-    const uint64_t excl = block_excl_scan_u64(sum, s_w, tot);
-    if (!WRITE) {
-        if (threadIdx.x == 0) tile_v[blockIdx.x] = tot;
-        return;
-    }
-    uint64_t run = tile_v[blockIdx.x] + excl;
-#pragma unroll
-    for (int i = 0; i < RS_ITEMS; i++) {
-        if (base + i < n_rec) {
-            out_byte_off[base + i] = run;
-            const bool raw = (frag_len[base + i] & OPAL_RAW_FLAG) != 0;
-            frag_off[base + i] = raw ? run : run * 4;          // packed fragments are addressed in bases
-        }
-        run += v[i];
-    }
-}
-
-// output bytes [b0, b1) of one record, strided over by `nthreads` threads of which this is number `tid`
-__device__ __forceinline__ void pack_span(const uint8_t *__restrict__ seq, uint64_t s, uint64_t len, bool raw, uint8_t *__restrict__ dst,
-                                          uint64_t b0, uint64_t b1, uint64_t tid, uint64_t nthreads)
-{
-    if (raw) {
-        for (uint64_t i = b0 + tid; i < b1; i += nthreads) dst[i] = seq[s + i];
-        return;
-    }
-    // 4 letters per output byte: two aligned dwords + v_alignbyte instead of four byte loads (seq has 16 bytes of
-    // slack behind its last byte), then all four codes at once
-    const uint32_t *__restrict__ seq4 = reinterpret_cast<const uint32_t *>(seq);
-    for (uint64_t b = b0 + tid; b < b1; b += nthreads) {
-        const uint64_t a = s + 4 * b;
-        const uint32_t x = __builtin_amdgcn_alignbyte(seq4[(a >> 2) + 1], seq4[a >> 2], (uint32_t)(a & 3));
-        // A=0x41 C=0x43 G=0x47 T=0x54: (ch >> 1) & 3 gives 0,1,3,2 -> fix the G/T order
-        uint32_t q = (x >> 1) & 0x03030303u;
-        q ^= (q >> 1) & 0x01010101u;
-        const uint64_t left = len - 4 * b;                                    // letters of the record from here on (>= 1)
-        if (left < 4) q &= (1u << (8 * (uint32_t)left)) - 1u;
-        dst[b] = (uint8_t)((q | (q >> 6) | (q >> 12) | (q >> 18)) & 0xffu);
-    }
-}
-
-// one wave per record: write the packed (4 bases/byte) or raw copy.  Records on the long list are left to
-// ing_pack_long_kernel (unless the list overflowed: then every record is handled here).
-__global__ __launch_bounds__(BLOCK) void ing_pack_kernel(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ seq_start,
-                                                          const uint32_t *__restrict__ frag_len, const uint64_t *__restrict__ out_byte_off,
-                                                          uint64_t n_rec, uint8_t *__restrict__ out, uint64_t out_cap,
-                                                          const unsigned int *__restrict__ long_count)
-{
-    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
-    const uint64_t nwaves = (uint64_t)gridDim.x * WPB;
-    const bool split_long = *long_count <= LONG_CAP;
-    for (uint64_t r = (uint64_t)blockIdx.x * WPB + wv; r < n_rec; r += nwaves) {
-        const uint32_t lw = frag_len[r];
-        const uint64_t len = lw & ~OPAL_RAW_FLAG;
-        if (split_long && len > LONG_BASES) continue;
-        const bool raw = (lw & OPAL_RAW_FLAG) != 0;
-        const uint64_t o = out_byte_off[r], nb = raw ? len : (len + 3) / 4;
-        if (o + nb > out_cap) continue;
-        pack_span(seq, seq_start[r], len, raw, out + o, 0, nb, (uint64_t)lane, WAVE);
-    }
-}
-
-// the long records (genomes), one after the other, each spread over the whole grid
-__global__ __launch_bounds__(BLOCK) void ing_pack_long_kernel(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ seq_start,
-                                                               const uint32_t *__restrict__ frag_len, const uint64_t *__restrict__ out_byte_off,
-                                                               uint8_t *__restrict__ out, uint64_t out_cap,
-                                                               const unsigned int *__restrict__ long_count, const uint64_t *__restrict__ long_list)
-{
-    const unsigned int n_long = *long_count;
-    if (n_long > LONG_CAP) return;
-    const uint64_t tid = (uint64_t)blockIdx.x * BLOCK + threadIdx.x, nthreads = (uint64_t)gridDim.x * BLOCK;
-    for (unsigned int li = 0; li < n_long; li++) {
-        const uint64_t r = long_list[li];
-        const uint32_t lw = frag_len[r];
-        const uint64_t len = lw & ~OPAL_RAW_FLAG;
-        const bool raw = (lw & OPAL_RAW_FLAG) != 0;
-        const uint64_t o = out_byte_off[r], nb = raw ? len : (len + 3) / 4;
-        if (o + nb > out_cap) continue;
-        pack_span(seq, seq_start[r], len, raw, out + o, 0, nb, tid, nthreads);
     }
 }
 
@@ -456,81 +505,54 @@ extern "C" int opal_ingest_fasta(opal_ctx *ctx, const uint8_t *d_text, uint64_t 
     if (nbytes == 0) return OPAL_OK;
     if (!d_text || !d_reads_out || !d_frag_off || !d_frag_len) return opal::fail(ctx, OPAL_EINVAL, "opal_ingest_fasta: null device pointer");
     if (max_records == 0) return opal::fail(ctx, OPAL_EINVAL, "opal_ingest_fasta: max_records is 0");
+    if (reinterpret_cast<uintptr_t>(d_reads_out) & 3u) return opal::fail(ctx, OPAL_EINVAL, "opal_ingest_fasta: d_reads_out must be 4-byte aligned");
     OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const uint64_t ntiles = (nbytes + ING_TILE - 1) / ING_TILE;
-    // scratch: [tile states | tile counts | totals] , compacted text, record starts, record bytes/offsets
-    int rc = grow(ctx, &ctx->ing_tiles, &ctx->ing_tiles_cap, ntiles * (sizeof(St) + sizeof(uint64_t)) + 256);
+    if (ntiles > 0x7fffffffull) return opal::fail(ctx, OPAL_EINVAL, "opal_ingest_fasta: text too large for one call (32 TiB)");
+    // scratch: [tile summaries | tile states | fin], [record starts | raw flags]
+    int rc = grow(ctx, &ctx->ing_tiles, &ctx->ing_tiles_cap, ntiles * (sizeof(Sum) + sizeof(Pre)) + F_WORDS * sizeof(uint64_t) + 256);
     if (rc) return rc;
-    rc = grow(ctx, &ctx->ing_seq, &ctx->ing_seq_cap, nbytes + 16);   // slack: the packer reads whole dwords
+    rc = grow(ctx, &ctx->ing_rec, &ctx->ing_rec_cap, (max_records + 1) * (sizeof(uint64_t) + sizeof(uint32_t)) + 256);
     if (rc) return rc;
-    const uint64_t rec_tiles = (max_records + RS_TILE - 1) / RS_TILE;
-    rc = grow(ctx, &ctx->ing_rec, &ctx->ing_rec_cap, (max_records + 1) * (3 * sizeof(uint64_t) + sizeof(uint32_t)) +
-                                                       (rec_tiles + LONG_CAP) * sizeof(uint64_t) + 256);
-    if (rc) return rc;
-    St *tile_st = (St *)ctx->ing_tiles;
-    uint64_t *tile_cnt = (uint64_t *)(tile_st + ntiles);
-    St *total_st = (St *)(tile_cnt + ntiles);                    // 16 bytes
-    uint64_t *total_cnt = (uint64_t *)(total_st + 1);
-    uint64_t *total_out = total_cnt + 1;
-    uint64_t *too_long = total_out + 1;
-    uint8_t *seq = (uint8_t *)ctx->ing_seq;
+    Pre *tile_pre = (Pre *)ctx->ing_tiles;                       // 24-byte entries, 8-byte aligned
+    uint64_t *fin = (uint64_t *)(tile_pre + ntiles);
+    Sum *tile_sum = (Sum *)(fin + F_WORDS);
     uint64_t *seq_start = (uint64_t *)ctx->ing_rec;
-    uint64_t *rec_bytes = seq_start + (max_records + 1);
-    uint64_t *out_byte_off = rec_bytes + (max_records + 1);
-    uint64_t *rec_tile_v = out_byte_off + (max_records + 1);
-    uint64_t *long_list = rec_tile_v + rec_tiles;
-    unsigned int *long_count = (unsigned int *)(long_list + LONG_CAP);      // 2 x u32 (8-byte slot)
-    uint32_t *raw_flag = (uint32_t *)(long_count + 2);
-
-    hipLaunchKernelGGL(ing_tile_state_kernel, dim3((unsigned)ntiles), dim3(BLOCK), 0, st, d_text, nbytes, tile_st);
-    hipLaunchKernelGGL(ing_scan_tiles_st_kernel, dim3(1), dim3(BLOCK), 0, st, tile_st, ntiles, total_st);
-    hipLaunchKernelGGL(ing_content_kernel<false>, dim3((unsigned)ntiles), dim3(BLOCK), 0, st, d_text, nbytes, tile_st, total_st, tile_cnt,
-                       seq, seq_start, max_records);
-    hipLaunchKernelGGL(ing_scan_tiles_u64_kernel, dim3(1), dim3(BLOCK), 0, st, tile_cnt, ntiles, total_cnt);
-    // a file without any '>' is one record that starts at 0
-    OPAL_HIP_CHECK(ctx, hipMemsetAsync(seq_start, 0, sizeof(uint64_t), st));
-    hipLaunchKernelGGL(ing_content_kernel<true>, dim3((unsigned)ntiles), dim3(BLOCK), 0, st, d_text, nbytes, tile_st, total_st, tile_cnt,
-                       seq, seq_start, max_records);
+    uint32_t *raw_flag = (uint32_t *)(seq_start + (max_records + 1));
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(d_reads_out);
+    const uint64_t cap_words = reads_cap / 4;
+    // the packed stream is assembled with atomic ORs where tiles meet: zero what it can reach (T <= nbytes bases)
+    const uint64_t zero_words = std::min<uint64_t>(cap_words, nbytes / 16 + 2);
+    OPAL_HIP_CHECK(ctx, hipMemsetAsync(out32, 0, zero_words * 4, st));
+    OPAL_HIP_CHECK(ctx, hipMemsetAsync(fin, 0, F_WORDS * sizeof(uint64_t), st));
+    OPAL_HIP_CHECK(ctx, hipMemsetAsync(seq_start, 0, sizeof(uint64_t), st));   // a file without any '>' is one record that starts at 0
+    OPAL_HIP_CHECK(ctx, hipMemsetAsync(raw_flag, 0, max_records * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(ing_summary_kernel, dim3((unsigned)ntiles), dim3(BLOCK), 0, st, d_text, nbytes, tile_sum);
+    hipLaunchKernelGGL(ing_scan_kernel, dim3(1), dim3(BLOCK), 0, st, tile_sum, ntiles, tile_pre, fin);
+    hipLaunchKernelGGL(ing_pack_kernel<false>, dim3((unsigned)ntiles), dim3(BLOCK), 0, st, d_text, nbytes, tile_pre, fin, out32, cap_words,
+                       seq_start, raw_flag, max_records, d_reads_out, reads_cap, d_frag_off);
+    const int rgrid = (int)std::max<uint64_t>(1, std::min<uint64_t>((max_records + BLOCK - 1) / BLOCK, (uint64_t)ctx->num_cus * 8));
+    hipLaunchKernelGGL(ing_records_kernel, dim3(rgrid), dim3(BLOCK), 0, st, seq_start, raw_flag, fin, max_records, reads_cap, d_frag_off,
+                       d_frag_len);
     OPAL_HIP_CHECK(ctx, hipGetLastError());
-    struct { St s; uint64_t content; } host;
-    OPAL_HIP_CHECK(ctx, hipMemcpyAsync(&host, total_st, sizeof(host), hipMemcpyDeviceToHost, st));
+    uint64_t host[F_WORDS];
+    OPAL_HIP_CHECK(ctx, hipMemcpyAsync(host, fin, sizeof(host), hipMemcpyDeviceToHost, st));
     OPAL_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    const uint64_t T = host.content;
-    uint64_t n_rec = host.s.h ? host.s.h : (T ? 1 : 0);
-    if (n_rec > max_records) return opal::fail(ctx, OPAL_ERANGE, "opal_ingest_fasta: more records than max_records");
-    if (n_rec && host.s.h) {
-        // the last record is dropped when its sequence is empty (fasta_functions.py:20-22)
-        uint64_t last_start = 0;
-        OPAL_HIP_CHECK(ctx, hipMemcpyAsync(&last_start, seq_start + (n_rec - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-        OPAL_HIP_CHECK(ctx, hipStreamSynchronize(st));
-        if (last_start == T) n_rec--;
-    }
+    const uint64_t H = host[F_H], T = host[F_T];
+    if (H > max_records) return opal::fail(ctx, OPAL_ERANGE, "opal_ingest_fasta: more records than max_records");
+    if (host[F_TOOLONG]) return opal::fail(ctx, OPAL_EINVAL, "opal_ingest_fasta: a record is longer than 2^31-1 bases");
+    const uint64_t n_rec = (H ? H : (T ? 1 : 0)) - (host[F_DROPPED] ? 1 : 0);
     *n_records_out = n_rec;
     if (n_rec == 0) return OPAL_OK;
-    const int wgrid = (int)std::max<uint64_t>(1, std::min<uint64_t>((n_rec + WPB - 1) / WPB, (uint64_t)ctx->num_cus * 8));
-    OPAL_HIP_CHECK(ctx, hipMemsetAsync(too_long, 0, sizeof(uint64_t), st));
-    OPAL_HIP_CHECK(ctx, hipMemsetAsync(long_count, 0, 2 * sizeof(unsigned int) + n_rec * sizeof(uint32_t), st));   // count + flags
-    const int fgrid = ctx->num_cus * 8;
-    if (T) hipLaunchKernelGGL(ing_classify_kernel, dim3(fgrid), dim3(BLOCK), 0, st, seq, seq_start, n_rec, T, raw_flag);
-    hipLaunchKernelGGL(ing_lens_kernel, dim3((unsigned)std::min<uint64_t>((n_rec + BLOCK - 1) / BLOCK, (uint64_t)fgrid)), dim3(BLOCK), 0, st,
-                       seq_start, n_rec, T, raw_flag, d_frag_len, rec_bytes, too_long, long_count, long_list);
-    const uint64_t rt = (n_rec + RS_TILE - 1) / RS_TILE;
-    hipLaunchKernelGGL(ing_rec_scan_kernel<false>, dim3((unsigned)rt), dim3(BLOCK), 0, st, rec_bytes, d_frag_len, n_rec, rec_tile_v, out_byte_off, d_frag_off);
-    hipLaunchKernelGGL(ing_scan_tiles_u64_kernel, dim3(1), dim3(BLOCK), 0, st, rec_tile_v, rt, total_out);
-    hipLaunchKernelGGL(ing_rec_scan_kernel<true>, dim3((unsigned)rt), dim3(BLOCK), 0, st, rec_bytes, d_frag_len, n_rec, rec_tile_v, out_byte_off, d_frag_off);
-    OPAL_HIP_CHECK(ctx, hipGetLastError());
-    uint64_t tail[2] = {0, 0};   // {packed bytes, any record longer than 2^31-1}
-    OPAL_HIP_CHECK(ctx, hipMemcpyAsync(tail, total_out, sizeof(tail), hipMemcpyDeviceToHost, st));
-    OPAL_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    const uint64_t out_bytes = tail[0];
-    if (tail[1]) return opal::fail(ctx, OPAL_EINVAL, "opal_ingest_fasta: a record is longer than 2^31-1 bases");
-    if (out_bytes > reads_cap) return opal::fail(ctx, OPAL_ERANGE, "opal_ingest_fasta: d_reads_out too small");
-    hipLaunchKernelGGL(ing_pack_kernel, dim3(wgrid), dim3(BLOCK), 0, st, seq, seq_start, d_frag_len, out_byte_off, n_rec, d_reads_out, reads_cap,
-                       long_count);
-    hipLaunchKernelGGL(ing_pack_long_kernel, dim3(fgrid), dim3(BLOCK), 0, st, seq, seq_start, d_frag_len, out_byte_off, d_reads_out, reads_cap,
-                       long_count, long_list);
-    OPAL_HIP_CHECK(ctx, hipGetLastError());
+    const uint64_t out_bytes = host[F_NRAW] ? host[F_CURSOR] : ((T + 3) / 4 + 3) & ~3ull;
+    if (out_bytes > reads_cap || host[F_OVERFLOW]) return opal::fail(ctx, OPAL_ERANGE, "opal_ingest_fasta: d_reads_out too small");
+    if (host[F_NRAW]) {
+        hipLaunchKernelGGL(ing_pack_kernel<true>, dim3((unsigned)ntiles), dim3(BLOCK), 0, st, d_text, nbytes, tile_pre, fin, out32, cap_words,
+                           seq_start, raw_flag, max_records, d_reads_out, reads_cap, d_frag_off);
+        OPAL_HIP_CHECK(ctx, hipGetLastError());
+        OPAL_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    }
     *reads_bytes_out = out_bytes;
     return OPAL_OK;
 }

@@ -30,8 +30,8 @@ struct opal_ctx {
     uint64_t *d_block_sums = nullptr;
     uint64_t block_sums_cap = 0;
     // scratch of the FASTA ingest (grown on demand)
-    void *ing_tiles = nullptr, *ing_seq = nullptr, *ing_rec = nullptr;
-    uint64_t ing_tiles_cap = 0, ing_seq_cap = 0, ing_rec_cap = 0;
+    void *ing_tiles = nullptr, *ing_rec = nullptr;
+    uint64_t ing_tiles_cap = 0, ing_rec_cap = 0;
     std::string err;
 };
 

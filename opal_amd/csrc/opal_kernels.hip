@@ -359,7 +359,6 @@ extern "C" int opal_ctx_destroy(opal_ctx *ctx)
     if (ctx->d_w) (void)hipFree(ctx->d_w);
     if (ctx->d_g2) (void)hipFree(ctx->d_g2);
     if (ctx->ing_tiles) (void)hipFree(ctx->ing_tiles);
-    if (ctx->ing_seq) (void)hipFree(ctx->ing_seq);
     if (ctx->ing_rec) (void)hipFree(ctx->ing_rec);
     if (ctx->d_block_sums) (void)hipFree(ctx->d_block_sums);
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);

@@ -37,6 +37,21 @@ class PackedReads:
         self.data, self.off, self.len = data, off, length
         self.n = int(len(off))
 
+    def sequences(self):
+        """Decodes the batch back into the text of its records (list of bytes): packed fragments are addressed in
+        bases and may start anywhere inside a byte, raw ones in bytes (include/opal_hip.h)."""
+        acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+        data = np.asarray(self.data, dtype=np.uint8)
+        out = []
+        for o, lw in zip(self.off.tolist(), self.len.tolist()):
+            ln = lw & 0x7FFFFFFF
+            if lw & _lib.RAW_FLAG:
+                out.append(data[o:o + ln].tobytes())
+            else:
+                p = np.arange(o, o + ln, dtype=np.uint64)
+                out.append(acgt[(data[(p >> np.uint64(2)).astype(np.int64)] >> ((p & np.uint64(3)) * np.uint64(2)).astype(np.uint8)) & 3].tobytes())
+        return out
+
     @staticmethod
     def from_blob(blob: np.ndarray, seq_off: np.ndarray):
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
@@ -328,10 +343,11 @@ class Engine:
             return self.upload(PackedReads.from_sequences([]))
         d_text = t.from_numpy(arr.copy() if not arr.flags.writeable else arr).to(self.device)
         max_rec = int((d_text == 62).sum().item()) + 1          # number of '>' bytes bounds the record count
-        reads = t.empty(n, dtype=t.uint8, device=self.device)
+        cap = n + n // 4 + 64                                    # packed stream of every sequence byte + raw records
+        reads = t.empty(cap, dtype=t.uint8, device=self.device)
         off = t.empty(max_rec, dtype=t.int64, device=self.device)
         ln = t.empty(max_rec, dtype=t.int32, device=self.device)
         nrec, nb = C.c_uint64(), C.c_uint64()
-        check(lib().opal_ingest_fasta(self._h, d_text.data_ptr(), n, reads.data_ptr(), n, off.data_ptr(), ln.data_ptr(), max_rec,
+        check(lib().opal_ingest_fasta(self._h, d_text.data_ptr(), n, reads.data_ptr(), cap, off.data_ptr(), ln.data_ptr(), max_rec,
                                       C.byref(nrec), C.byref(nb)), self._h)
         return DeviceBatch(reads, off, ln, int(nrec.value), max(int(nb.value), 1))

@@ -313,16 +313,24 @@ def test_zero_copy_fragments_from_resident_genomes(amd, eng, oracle, golden_dir)
 
 
 def _check_ingest(amd, eng, oracle, text: bytes):
+    """The ingested batch decodes to exactly the records of the reference reader; records of upper-case ACGT are 2-bit
+    packed (views into one packed stream, addressed in bases), all others raw."""
     recs = oracle.fasta_read(text, universal_newlines=True)
-    want = amd.PackedReads.from_sequences([sq for _, sq in recs])
     b = eng.ingest_fasta(text)
     assert b.n == len(recs), (b.n, len(recs))
     if b.n == 0:
         return
-    assert np.array_equal(b.len.cpu().numpy()[:b.n].view(np.uint32), want.len)
-    assert np.array_equal(b.off.cpu().numpy()[:b.n].view(np.uint64), want.off)
-    nb = int(want.data.size) if want.len.size and (want.len & 0x7fffffff).sum() else 0
-    assert np.array_equal(b.data.cpu().numpy()[:nb], want.data[:nb])
+    ln = b.len.cpu().numpy()[:b.n].view(np.uint32)
+    want = amd.PackedReads.from_sequences([sq for _, sq in recs])
+    assert np.array_equal(ln, want.len)                       # lengths and the packed/raw decision of opal_pack_reads
+    got = amd.PackedReads(b.data.cpu().numpy()[:b.nbytes], b.off.cpu().numpy()[:b.n].view(np.uint64), ln)
+    assert got.sequences() == [sq for _, sq in recs]
+    # raw records never overlap each other or the packed stream
+    spans = sorted((int(o), int(o) + int(l & 0x7fffffff)) for o, l in zip(got.off, ln) if l & 0x80000000)
+    stream_end = (sum(len(sq) for _, sq in recs) + 3) // 4
+    for (a0, a1), (b0, _) in zip(spans, spans[1:]):
+        assert a1 <= b0
+    assert all(a0 >= stream_end and a1 <= b.nbytes for a0, a1 in spans)
 
 
 def test_gpu_fasta_ingest_matches_reference_reader(amd, eng, oracle, golden_dir):
