@@ -169,6 +169,14 @@ int opal_ingest_fasta(opal_ctx *ctx, const uint8_t *d_text, uint64_t nbytes, uin
                       uint64_t *d_frag_off, uint32_t *d_frag_len, uint64_t max_records, uint64_t *n_records_out,
                       uint64_t *reads_bytes_out);
 
+/* First half of opal_ingest_fasta on its own (two of its three passes): the number of '>' header lines (the record
+ * count, or one less when the last record is empty; a text without any header is one record) and of sequence bytes
+ * in the text, so that the caller can size d_frag_off / d_frag_len (max_records = max(headers, 1)) and d_reads_out
+ * (seq_bytes/4 + 64 if every record is upper-case ACGT, plus the bytes of the records that are not: at most seq_bytes
+ * more).  The ctx keeps the result: an opal_ingest_fasta call on the same (d_text, nbytes) that directly follows skips
+ * those passes (the text must not change in between).  Synchronises the stream.                                 */
+int opal_ingest_scan(opal_ctx *ctx, const uint8_t *d_text, uint64_t nbytes, uint64_t *n_headers_out, uint64_t *seq_bytes_out);
+
 /* Evaluation counts.  Replaces the string compare + groupby of opal.evaluate_predictions (opal.py:111-131):
  * d_total[c] = number of fragments whose reference class is c, d_correct[c] = those predicted as c.
  * d_pred/d_ref: dense class ids in [0, n_classes) (ref) / any int (pred); both outputs are zeroed by the call.

@@ -41,6 +41,7 @@ PROTOTYPES = {
     "opal_feature_names": (_int, [_vp, _vp, _u64, _vp, _vp, _u64, _int, _vp, _vp, _u64]),
     "opal_predict": (_int, [_vp, _vp, _u64, _vp, _vp, _u64, _int, _vp, _vp]),
     "opal_predict_kernel_name": (C.c_char_p, [_vp]),
+    "opal_ingest_scan": (_int, [_vp, _vp, _u64, C.POINTER(_u64), C.POINTER(_u64)]),
     "opal_ingest_fasta": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, _vp, _u64, C.POINTER(_u64), C.POINTER(_u64)]),
     "opal_eval_counts": (_int, [_vp, _vp, _vp, _u64, _u32, _vp, _vp]),
     "opal_train_begin": (_int, [_vp, _int, _int, _int]),

@@ -494,11 +494,53 @@ int grow(opal_ctx *ctx, void **p, uint64_t *cap, uint64_t need)
 
 }  // namespace
 
+// passes 1-2: tile summaries and the state every tile starts in; fin[F_H], fin[F_T], fin[F_CURSOR] are set
+static int ingest_scan_passes(opal_ctx *ctx, const uint8_t *d_text, uint64_t nbytes, uint64_t ntiles)
+{
+    int rc = grow(ctx, &ctx->ing_tiles, &ctx->ing_tiles_cap, ntiles * (sizeof(Sum) + sizeof(Pre)) + F_WORDS * sizeof(uint64_t) + 256);
+    if (rc) return rc;
+    Pre *tile_pre = (Pre *)ctx->ing_tiles;                       // 24-byte entries, 8-byte aligned
+    uint64_t *fin = (uint64_t *)(tile_pre + ntiles);
+    Sum *tile_sum = (Sum *)(fin + F_WORDS);
+    OPAL_HIP_CHECK(ctx, hipMemsetAsync(fin, 0, F_WORDS * sizeof(uint64_t), ctx->stream));
+    hipLaunchKernelGGL(ing_summary_kernel, dim3((unsigned)ntiles), dim3(BLOCK), 0, ctx->stream, d_text, nbytes, tile_sum);
+    hipLaunchKernelGGL(ing_scan_kernel, dim3(1), dim3(BLOCK), 0, ctx->stream, tile_sum, ntiles, tile_pre, fin);
+    OPAL_HIP_CHECK(ctx, hipGetLastError());
+    return OPAL_OK;
+}
+
+extern "C" int opal_ingest_scan(opal_ctx *ctx, const uint8_t *d_text, uint64_t nbytes, uint64_t *n_headers_out, uint64_t *seq_bytes_out)
+{
+    if (!ctx) return opal::fail(nullptr, OPAL_EINVAL, "opal_ingest_scan: null ctx");
+    if (!n_headers_out || !seq_bytes_out) return opal::fail(ctx, OPAL_EINVAL, "opal_ingest_scan: null count outputs");
+    *n_headers_out = 0;
+    *seq_bytes_out = 0;
+    ctx->ing_scan_valid = false;
+    if (nbytes == 0) return OPAL_OK;
+    if (!d_text) return opal::fail(ctx, OPAL_EINVAL, "opal_ingest_scan: null device pointer");
+    OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint64_t ntiles = (nbytes + ING_TILE - 1) / ING_TILE;
+    if (ntiles > 0x7fffffffull) return opal::fail(ctx, OPAL_EINVAL, "opal_ingest_scan: text too large for one call (32 TiB)");
+    int rc = ingest_scan_passes(ctx, d_text, nbytes, ntiles);
+    if (rc) return rc;
+    uint64_t host[2];
+    OPAL_HIP_CHECK(ctx, hipMemcpyAsync(host, (uint64_t *)((Pre *)ctx->ing_tiles + ntiles), sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+    OPAL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    *n_headers_out = host[F_H];
+    *seq_bytes_out = host[F_T];
+    ctx->ing_scan_valid = true;
+    ctx->ing_scan_text = d_text;
+    ctx->ing_scan_nbytes = nbytes;
+    return OPAL_OK;
+}
+
 extern "C" int opal_ingest_fasta(opal_ctx *ctx, const uint8_t *d_text, uint64_t nbytes, uint8_t *d_reads_out, uint64_t reads_cap,
                                  uint64_t *d_frag_off, uint32_t *d_frag_len, uint64_t max_records, uint64_t *n_records_out,
                                  uint64_t *reads_bytes_out)
 {
     if (!ctx) return opal::fail(nullptr, OPAL_EINVAL, "opal_ingest_fasta: null ctx");
+    const bool scanned = ctx->ing_scan_valid && ctx->ing_scan_text == d_text && ctx->ing_scan_nbytes == nbytes;
+    ctx->ing_scan_valid = false;                                  // a scan serves the one call that follows it
     if (!n_records_out || !reads_bytes_out) return opal::fail(ctx, OPAL_EINVAL, "opal_ingest_fasta: null count outputs");
     *n_records_out = 0;
     *reads_bytes_out = 0;
@@ -510,14 +552,15 @@ extern "C" int opal_ingest_fasta(opal_ctx *ctx, const uint8_t *d_text, uint64_t 
     hipStream_t st = ctx->stream;
     const uint64_t ntiles = (nbytes + ING_TILE - 1) / ING_TILE;
     if (ntiles > 0x7fffffffull) return opal::fail(ctx, OPAL_EINVAL, "opal_ingest_fasta: text too large for one call (32 TiB)");
-    // scratch: [tile summaries | tile states | fin], [record starts | raw flags]
-    int rc = grow(ctx, &ctx->ing_tiles, &ctx->ing_tiles_cap, ntiles * (sizeof(Sum) + sizeof(Pre)) + F_WORDS * sizeof(uint64_t) + 256);
+    // scratch: [tile states | fin | tile summaries] (passes 1-2), [record starts | raw flags]
+    int rc = grow(ctx, &ctx->ing_rec, &ctx->ing_rec_cap, (max_records + 1) * (sizeof(uint64_t) + sizeof(uint32_t)) + 256);
     if (rc) return rc;
-    rc = grow(ctx, &ctx->ing_rec, &ctx->ing_rec_cap, (max_records + 1) * (sizeof(uint64_t) + sizeof(uint32_t)) + 256);
-    if (rc) return rc;
-    Pre *tile_pre = (Pre *)ctx->ing_tiles;                       // 24-byte entries, 8-byte aligned
+    if (!scanned) {
+        rc = ingest_scan_passes(ctx, d_text, nbytes, ntiles);
+        if (rc) return rc;
+    }
+    Pre *tile_pre = (Pre *)ctx->ing_tiles;
     uint64_t *fin = (uint64_t *)(tile_pre + ntiles);
-    Sum *tile_sum = (Sum *)(fin + F_WORDS);
     uint64_t *seq_start = (uint64_t *)ctx->ing_rec;
     uint32_t *raw_flag = (uint32_t *)(seq_start + (max_records + 1));
     uint32_t *out32 = reinterpret_cast<uint32_t *>(d_reads_out);
@@ -525,11 +568,8 @@ extern "C" int opal_ingest_fasta(opal_ctx *ctx, const uint8_t *d_text, uint64_t 
     // the packed stream is assembled with atomic ORs where tiles meet: zero what it can reach (T <= nbytes bases)
     const uint64_t zero_words = std::min<uint64_t>(cap_words, nbytes / 16 + 2);
     OPAL_HIP_CHECK(ctx, hipMemsetAsync(out32, 0, zero_words * 4, st));
-    OPAL_HIP_CHECK(ctx, hipMemsetAsync(fin, 0, F_WORDS * sizeof(uint64_t), st));
     OPAL_HIP_CHECK(ctx, hipMemsetAsync(seq_start, 0, sizeof(uint64_t), st));   // a file without any '>' is one record that starts at 0
     OPAL_HIP_CHECK(ctx, hipMemsetAsync(raw_flag, 0, max_records * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(ing_summary_kernel, dim3((unsigned)ntiles), dim3(BLOCK), 0, st, d_text, nbytes, tile_sum);
-    hipLaunchKernelGGL(ing_scan_kernel, dim3(1), dim3(BLOCK), 0, st, tile_sum, ntiles, tile_pre, fin);
     hipLaunchKernelGGL(ing_pack_kernel<false>, dim3((unsigned)ntiles), dim3(BLOCK), 0, st, d_text, nbytes, tile_pre, fin, out32, cap_words,
                        seq_start, raw_flag, max_records, d_reads_out, reads_cap, d_frag_off);
     const int rgrid = (int)std::max<uint64_t>(1, std::min<uint64_t>((max_records + BLOCK - 1) / BLOCK, (uint64_t)ctx->num_cus * 8));

@@ -342,12 +342,18 @@ class Engine:
         if n == 0:
             return self.upload(PackedReads.from_sequences([]))
         d_text = t.from_numpy(arr.copy() if not arr.flags.writeable else arr).to(self.device)
-        max_rec = int((d_text == 62).sum().item()) + 1          # number of '>' bytes bounds the record count
-        cap = n + n // 4 + 64                                    # packed stream of every sequence byte + raw records
-        reads = t.empty(cap, dtype=t.uint8, device=self.device)
+        nh, nseq = C.c_uint64(), C.c_uint64()
+        check(lib().opal_ingest_scan(self._h, d_text.data_ptr(), n, C.byref(nh), C.byref(nseq)), self._h)
+        max_rec, T = max(int(nh.value), 1), int(nseq.value)
         off = t.empty(max_rec, dtype=t.int64, device=self.device)
         ln = t.empty(max_rec, dtype=t.int32, device=self.device)
         nrec, nb = C.c_uint64(), C.c_uint64()
-        check(lib().opal_ingest_fasta(self._h, d_text.data_ptr(), n, reads.data_ptr(), cap, off.data_ptr(), ln.data_ptr(), max_rec,
-                                      C.byref(nrec), C.byref(nb)), self._h)
+        # room for the packed stream and a few raw records first; the full bound only if that turns out too small
+        for cap in (T // 4 + T // 32 + 4096, T // 4 + T + 64):
+            reads = t.empty(cap, dtype=t.uint8, device=self.device)
+            rc = lib().opal_ingest_fasta(self._h, d_text.data_ptr(), n, reads.data_ptr(), cap, off.data_ptr(), ln.data_ptr(), max_rec,
+                                         C.byref(nrec), C.byref(nb))
+            if rc != _lib.OPAL_ERANGE:
+                break
+        check(rc, self._h)
         return DeviceBatch(reads, off, ln, int(nrec.value), max(int(nb.value), 1))

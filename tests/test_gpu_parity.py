@@ -372,6 +372,31 @@ def test_gpu_fasta_ingest_matches_reference_reader(amd, eng, oracle, golden_dir)
     genomes = (b">short1\nACGTACGT\n>g1 packed genome\n" + wrapped(g1) + b">empty\n>g2 raw genome\n" + wrapped(bytes(g2), 61) +
                b">short2\nacgtn\n>g3\n" + wrapped(g3, 80) + b">edge\n" + wrapped(bytes(rng.choice(ACGT, size=65_536))))
     _check_ingest(amd, eng, oracle, genomes)
+    # the C-ABI without opal_ingest_scan in front (the call then runs all passes itself), an exact-fit and a too-small
+    # d_reads_out, too few record slots
+    import ctypes as C
+    import torch
+    from opal_amd._lib import OPAL_ERANGE, lib
+    d_text = torch.from_numpy(np.frombuffer(big, dtype=np.uint8).copy()).to(eng.device)
+    ref = eng.ingest_fasta(big)
+    max_rec = big.count(b">") + 1
+    off = torch.empty(max_rec, dtype=torch.int64, device=eng.device)
+    ln = torch.empty(max_rec, dtype=torch.int32, device=eng.device)
+    nrec, nb = C.c_uint64(), C.c_uint64()
+    for cap, want_rc in ((ref.nbytes, 0), (ref.nbytes - 4, OPAL_ERANGE), (len(big) * 2, 0)):
+        reads = torch.full((cap + 64,), 0xEE, dtype=torch.uint8, device=eng.device)
+        rc = lib().opal_ingest_fasta(eng._h, d_text.data_ptr(), len(big), reads.data_ptr(), cap, off.data_ptr(), ln.data_ptr(), max_rec,
+                                     C.byref(nrec), C.byref(nb))
+        assert rc == want_rc, (cap, rc)
+        assert bool((reads[cap:] == 0xEE).all())                # never writes past reads_cap
+        if rc == 0:
+            assert nrec.value == ref.n and nb.value == ref.nbytes
+            got = amd.PackedReads(reads.cpu().numpy()[:nb.value], off.cpu().numpy()[:ref.n].view(np.uint64),
+                                  ln.cpu().numpy()[:ref.n].view(np.uint32))
+            assert got.sequences() == [sq for _, sq in oracle.fasta_read(big, universal_newlines=True)]
+    rc = lib().opal_ingest_fasta(eng._h, d_text.data_ptr(), len(big), reads.data_ptr(), len(big) * 2, off.data_ptr(), ln.data_ptr(), 100,
+                                 C.byref(nrec), C.byref(nb))
+    assert rc == OPAL_ERANGE
     # end to end: predictions from the ingested batch equal predictions from host-parsed records
     pos = _patterns(amd, golden_dir, "patterns_k64_t16_m1_s7.txt", 64)
     eng.set_patterns(pos, 64)
