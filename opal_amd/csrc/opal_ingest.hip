@@ -93,8 +93,9 @@ __device__ __forceinline__ Pre pre_apply(const Pre &p, const Sum &s)
     return r;
 }
 
-// Block-wide scan of per-thread summaries (256 threads): returns this thread's exclusive prefix, the block total
+// Block-wide scan of per-thread summaries (NW waves): returns this thread's exclusive prefix, the block total
 // through `total`.  Contains two __syncthreads.
+template <int NW = WPB>
 __device__ __forceinline__ Sum block_excl_scan_sum(const Sum &v, Sum *s_w, Sum &total)
 {
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
@@ -109,7 +110,7 @@ __device__ __forceinline__ Sum block_excl_scan_sum(const Sum &v, Sum *s_w, Sum &
     Sum base = sum_identity();
     total = sum_identity();
 #pragma unroll
-    for (int w = 0; w < WPB; w++) {
+    for (int w = 0; w < NW; w++) {
         if (w < wv) base = sum_combine(base, s_w[w]);
         total = sum_combine(total, s_w[w]);
     }
@@ -288,14 +289,16 @@ __global__ __launch_bounds__(BLOCK) void ing_summary_kernel(const uint8_t *__res
 //      [3] raw records, [4] a record is longer than 2^31-1, [5] the last record is empty (dropped), [6] raw area overflow
 enum { F_H = 0, F_T, F_CURSOR, F_NRAW, F_TOOLONG, F_DROPPED, F_OVERFLOW, F_WORDS = 8 };
 constexpr int SC_ITEMS = 8;
-__global__ __launch_bounds__(BLOCK) void ing_scan_kernel(const Sum *__restrict__ tile_sum, uint64_t ntiles, Pre *__restrict__ tile_pre,
+constexpr int SC_WAVES = 16;                       // one block of 1024 threads: the scan is a chain of short rounds
+constexpr int SC_BLOCK = SC_WAVES * WAVE;
+__global__ __launch_bounds__(SC_BLOCK) void ing_scan_kernel(const Sum *__restrict__ tile_sum, uint64_t ntiles, Pre *__restrict__ tile_pre,
                                                           uint64_t *__restrict__ fin)
 {
-    __shared__ Sum s_w[WPB];
+    __shared__ Sum s_w[SC_WAVES];
     __shared__ Pre s_carry;
     if (threadIdx.x == 0) s_carry = Pre{0, 0, 0, 0};
     __syncthreads();
-    for (uint64_t b0 = 0; b0 < ntiles; b0 += (uint64_t)BLOCK * SC_ITEMS) {   // 2048 tiles = 32 MiB of text: u32 counts hold
+    for (uint64_t b0 = 0; b0 < ntiles; b0 += (uint64_t)SC_BLOCK * SC_ITEMS) {   // 8192 tiles = 128 MiB of text: u32 counts hold
         const uint64_t i0 = b0 + (uint64_t)threadIdx.x * SC_ITEMS;
         Sum v[SC_ITEMS], agg = sum_identity();
 #pragma unroll
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(BLOCK) void ing_scan_kernel(const Sum *__restrict__
             agg = sum_combine(agg, v[j]);
         }
         Sum total;
-        const Sum excl = block_excl_scan_sum(agg, s_w, total);
+        const Sum excl = block_excl_scan_sum<SC_WAVES>(agg, s_w, total);
         const Pre carry = s_carry;
         Pre run = pre_apply(carry, excl);
 #pragma unroll
@@ -504,7 +507,7 @@ static int ingest_scan_passes(opal_ctx *ctx, const uint8_t *d_text, uint64_t nby
     Sum *tile_sum = (Sum *)(fin + F_WORDS);
     OPAL_HIP_CHECK(ctx, hipMemsetAsync(fin, 0, F_WORDS * sizeof(uint64_t), ctx->stream));
     hipLaunchKernelGGL(ing_summary_kernel, dim3((unsigned)ntiles), dim3(BLOCK), 0, ctx->stream, d_text, nbytes, tile_sum);
-    hipLaunchKernelGGL(ing_scan_kernel, dim3(1), dim3(BLOCK), 0, ctx->stream, tile_sum, ntiles, tile_pre, fin);
+    hipLaunchKernelGGL(ing_scan_kernel, dim3(1), dim3(SC_BLOCK), 0, ctx->stream, tile_sum, ntiles, tile_pre, fin);
     OPAL_HIP_CHECK(ctx, hipGetLastError());
     return OPAL_OK;
 }

@@ -23,9 +23,10 @@ def reads_fasta(n, L=200):
     for d in range(8):
         rec[:, 8 - d] = ord("0") + (ids // 10 ** d) % 10
     rec[:, 9] = ord("\n")
-    rec[:, 10:10 + L] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, L), dtype=np.uint8)]
+    codes = rng.integers(0, 4, size=(n, L), dtype=np.uint8)
+    rec[:, 10:10 + L] = np.frombuffer(b"ACGT", dtype=np.uint8)[codes]
     rec[:, 10 + L] = ord("\n")
-    return rec.reshape(-1)
+    return rec.reshape(-1), codes
 
 
 def genome_fasta(n_genomes, length, width=70):
@@ -42,10 +43,10 @@ eng = amd.Engine(0)
 which = sys.argv[2] if len(sys.argv) > 2 else "both"
 cases = []
 if which in ("both", "reads"):
-    cases.append(("reads (%d x 200 bp)" % n, reads_fasta(n)))
+    cases.append(("reads (%d x 200 bp)" % n,) + reads_fasta(n))
 if which in ("both", "genomes"):
-    cases.append(("genomes (64 x 4 Mbp, 70-column lines)", genome_fasta(64, 4_000_000)))
-for name, arr in cases:
+    cases.append(("genomes (64 x 4 Mbp, 70-column lines)", genome_fasta(64, 4_000_000), None))
+for name, arr, codes in cases:
     d_text = torch.from_numpy(arr).to(eng.device)
     nbytes = int(arr.size)
     max_rec = int((d_text == 62).sum().item()) + 1
@@ -59,6 +60,12 @@ for name, arr in cases:
                                       max_rec, C.byref(nrec), C.byref(nb)), eng._h)
     run()
     torch.cuda.synchronize()
+    if codes is not None:
+        # every record is a 200-base view into the packed stream: the stream is the batch from_codes builds
+        want = amd.PackedReads.from_codes(codes)
+        assert nrec.value == n and np.array_equal(off.cpu().numpy()[:n].view(np.uint64), want.off)
+        assert bool((ln[:n] == 200).all()) and np.array_equal(reads.cpu().numpy()[:want.data.size], want.data)
+        print("verified: all %d records decode to the generated reads" % n, flush=True)
     t0 = time.perf_counter()
     for _ in range(5):
         run()

@@ -409,6 +409,39 @@ def test_gpu_fasta_ingest_matches_reference_reader(amd, eng, oracle, golden_dir)
     assert np.array_equal(c1.cpu().numpy(), c2.cpu().numpy())
 
 
+def test_gpu_fasta_ingest_at_scale(amd, eng):
+    """A 150 MB reads file (more tiles than one round of the tile scan holds, so the carried state is exercised) with
+    1000 raw records sprinkled in: every packed record is its 200-base view of the stream, every raw one decodes."""
+    n, L = 700_000, 200
+    rng = np.random.default_rng(77)
+    codes = rng.integers(0, 4, size=(n, L), dtype=np.uint8)
+    rec = np.empty((n, 10 + L + 1), dtype=np.uint8)
+    rec[:, 0] = ord(">")
+    ids = np.arange(n)
+    for d in range(8):
+        rec[:, 8 - d] = ord("0") + (ids // 10 ** d) % 10
+    rec[:, 9] = ord("\n")
+    rec[:, 10:10 + L] = ACGT[codes]
+    rec[:, 10 + L] = ord("\n")
+    raw_rows = np.sort(rng.choice(n, size=1000, replace=False))
+    rec[raw_rows, 10 + rng.integers(0, L, size=1000)] = ord("N")
+    assert rec.size > 8192 * 16384
+    b = eng.ingest_fasta(rec.reshape(-1))
+    assert b.n == n
+    ln = b.len.cpu().numpy()[:n].view(np.uint32)
+    off = b.off.cpu().numpy()[:n].view(np.uint64)
+    is_raw = np.zeros(n, dtype=bool)
+    is_raw[raw_rows] = True
+    assert np.array_equal(ln, np.where(is_raw, np.uint32(0x80000000 | L), np.uint32(L)))
+    want = amd.PackedReads.from_codes(codes)
+    assert np.array_equal(off[~is_raw], want.off[~is_raw])          # record i starts at base 200*i of the stream
+    data = b.data.cpu().numpy()
+    assert np.array_equal(data[:n * 50].reshape(n, 50)[~is_raw], want.data.reshape(n, 50)[~is_raw])
+    got = amd.PackedReads(data[:b.nbytes], off[raw_rows], ln[raw_rows]).sequences()
+    assert got == [rec[i, 10:10 + L].tobytes() for i in raw_rows]
+    assert int(off[raw_rows].min()) >= n * 50 and len(set(off[raw_rows].tolist())) == 1000
+
+
 def test_full_size_configs_properties(amd, oracle, golden_dir):
     """BASELINE.json configs 2 and 3 at their real sizes (1M x 200bp, K=356 / K=1564 shard, 2^31-slot table):
     size-independent properties + the oracle on a bounded sample."""
