@@ -1,5 +1,6 @@
 // Host-side half of libopal_hip.so: error plumbing, read packing, and the CPython-exact fragment sampler.
 // Nothing here touches the GPU.
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -73,6 +74,11 @@ extern "C" int opal_pack_reads(const uint8_t *seqs, const uint64_t *seq_off, uin
 // MT19937 exactly as CPython seeds and consumes it: random.seed(int) -> init_by_array(limbs of |seed|),
 // randint(0,n-1) -> _randbelow_with_getrandbits(n) = getrandbits(bit_length(n)) with rejection,
 // getrandbits(k<=32) = genrand >> (32-k), k>32 = little-endian words with the top one shifted.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define OPAL_HOST_CLONES                      // hipcc also parses this file for the device, where there is nothing to clone
+#else
+#define OPAL_HOST_CLONES __attribute__((target_clones("avx2", "default")))   // picked at load time by the host CPU
+#endif
 struct opal_rng {
     static constexpr int N = 624, M = 397;
     uint32_t s[N];
@@ -99,23 +105,31 @@ struct opal_rng {
         }
         s[0] = 0x80000000u;
     }
-    void refill()
+    // One twist of the whole state followed by the tempering of all 624 outputs into out[]: both loops are free of
+    // loop-carried dependencies inside their three segments (i+M reads the previous state for i < N-M and the new one
+    // after), so the compiler vectorises them; the consumers below then only index out[].
+    uint32_t out[N];
+    OPAL_HOST_CLONES void refill()
     {
-        auto tw = [](uint32_t u, uint32_t v) { return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u); };
+        auto tw = [](uint32_t u, uint32_t v) { return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((0u - (v & 1u)) & 0x9908b0dfu); };
         for (int i = 0; i < N - M; i++) s[i] = s[i + M] ^ tw(s[i], s[i + 1]);
-        for (int i = N - M; i < N - 1; i++) s[i] = s[i + M - N] ^ tw(s[i], s[i + 1]);
+        for (int i = N - M; i < 2 * (N - M); i++) s[i] = s[i + M - N] ^ tw(s[i], s[i + 1]);
+        for (int i = 2 * (N - M); i < N - 1; i++) s[i] = s[i + M - N] ^ tw(s[i], s[i + 1]);
         s[N - 1] = s[M - 1] ^ tw(s[N - 1], s[0]);
+        for (int i = 0; i < N; i++) {
+            uint32_t y = s[i];
+            y ^= y >> 11;
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= y >> 18;
+            out[i] = y;
+        }
         idx = 0;
     }
     uint32_t next()
     {
         if (idx >= N) refill();
-        uint32_t y = s[idx++];
-        y ^= y >> 11;
-        y ^= (y << 7) & 0x9d2c5680u;
-        y ^= (y << 15) & 0xefc60000u;
-        y ^= y >> 18;
-        return y;
+        return out[idx++];
     }
     uint64_t getrandbits(int k)
     {
@@ -170,14 +184,49 @@ extern "C" int opal_sample_positions(opal_rng *rng, const uint64_t *genome_len, 
         const uint64_t L = genome_len[g];
         if (L < frag_len) continue;                       // drawfrag.py:32-33, RNG untouched
         const double want = coverage * (double)L;         // drawfrag.py:31
-        uint64_t covered = 0, tries = 0;
-        while ((double)covered < want) {                  // drawfrag.py:36
-            tries++;
-            const uint64_t p = rng->randbelow(L - frag_len + 1);   // random.randint(0, len-k), drawfrag.py:38
-            covered += frag_len;
-            if (n < cap) { out_pos[n] = p; out_genome[n] = (uint32_t)g; }
-            n++;
-            if (tries > 10 * L) break;                    // drawfrag.py:48-49
+        const uint64_t range = L - frag_len + 1;          // random.randint(0, len-k), drawfrag.py:38
+        const int kbits = 64 - __builtin_clzll(range);
+        // the loop below runs `while coverage < c*len` (drawfrag.py:36) with coverage += frag_len per draw and the
+        // safety break `try_num > 10*len` (drawfrag.py:48-49): the number of draws is known in advance
+        uint64_t want_n = 0;                              // = number of t >= 0 with (double)(t*frag_len) < want
+        if (want > 0.0) {
+            const double q = want / (double)frag_len;
+            if (q > (double)(10 * L + 1)) want_n = 10 * L + 1;
+            else {
+                want_n = (uint64_t)q;
+                while ((double)(want_n * frag_len) < want) want_n++;
+                while (want_n > 0 && !((double)((want_n - 1) * frag_len) < want)) want_n--;
+                if (want_n > 10 * L + 1) want_n = 10 * L + 1;
+            }
+        }
+        if (kbits <= 32 && n + want_n <= cap) {
+            // _randbelow: getrandbits(kbits) = genrand >> (32-kbits), redrawn while >= range.  Branch-free over the
+            // tempered block: every output is stored, the write index only advances past accepted ones.
+            const int shift = 32 - kbits;
+            uint64_t got = 0;
+            while (got < want_n) {
+                if (rng->idx >= opal_rng::N) rng->refill();
+                int i = rng->idx;
+                const uint64_t room = want_n - got;
+                // at most `room` outputs can be accepted from min(room, rest of the block) candidates
+                const int end = (int)std::min<uint64_t>((uint64_t)opal_rng::N, (uint64_t)i + room);
+                uint64_t w = n + got;
+                for (; i < end; i++) {
+                    const uint64_t r = rng->out[i] >> shift;
+                    out_pos[w] = r;                       // slot w <= n + want_n - 1 < cap (overwritten if rejected)
+                    out_genome[w] = (uint32_t)g;
+                    w += r < range ? 1u : 0u;
+                }
+                got = w - n;
+                rng->idx = i;
+            }
+            n += want_n;
+        } else {
+            for (uint64_t t = 0; t < want_n; t++) {
+                const uint64_t p = rng->randbelow(range);
+                if (n < cap) { out_pos[n] = p; out_genome[n] = (uint32_t)g; }
+                n++;
+            }
         }
     }
     *n_out = n;
@@ -188,11 +237,25 @@ extern "C" int opal_sample_positions(opal_rng *rng, const uint64_t *genome_len, 
 extern "C" int opal_rng_shuffle(opal_rng *rng, uint64_t *perm, uint64_t n)
 {
     if (!rng || (!perm && n)) return opal::fail(nullptr, OPAL_EINVAL, "opal_rng_shuffle: bad arguments");
-    for (uint64_t i = n; i-- > 1;) {                      // Lib/random.py shuffle: reversed(range(1, n))
-        const uint64_t j = rng->randbelow(i + 1);
-        const uint64_t tmp = perm[i];
-        perm[i] = perm[j];
-        perm[j] = tmp;
+    // Lib/random.py shuffle: for i in reversed(range(1, n)): j = _randbelow(i+1); swap.  The draws do not depend on
+    // the array, so a block of them is made first and its targets prefetched (the swaps of a 10^7-entry array are
+    // cache misses), then the swaps run in the reference's order.
+    constexpr uint64_t B = 64;
+    uint64_t jbuf[B];
+    uint64_t i = n;
+    while (i > 1) {
+        const uint64_t m = std::min<uint64_t>(B, i - 1);
+        for (uint64_t t = 0; t < m; t++) {
+            jbuf[t] = rng->randbelow(i - t);              // step i-1-t draws from [0, i-1-t]
+            __builtin_prefetch(&perm[jbuf[t]], 1);
+        }
+        for (uint64_t t = 0; t < m; t++) {
+            const uint64_t a = i - 1 - t, j = jbuf[t];
+            const uint64_t tmp = perm[a];
+            perm[a] = perm[j];
+            perm[j] = tmp;
+        }
+        i -= m;
     }
     return OPAL_OK;
 }

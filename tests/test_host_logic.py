@@ -50,6 +50,48 @@ def test_rng_matches_cpython_golden(golden_dir):
         assert [r.randint(0, 999) for _ in range(5)] == c["after"]
 
 
+def test_block_sampler_equals_per_call_stream():
+    """opal_sample_positions consumes whole tempered blocks of the generator; it must draw exactly what a loop of
+    random.randint calls draws (drawfrag.py:36-49), for tiny ranges with many rejections, ranges just above and below a
+    power of two, genomes shorter than the fragment, fractional coverage, and leave the stream where that loop would."""
+    import opal_amd
+    cases = [
+        ([200, 201, 202, 203, 1000, 199, 5000], 200, 3.0),
+        ([1 << 12, (1 << 12) + 1, (1 << 12) - 1, (1 << 20) + 7], 1, 0.02),
+        ([300_000, 10, 70_001, 65_536 + 149], 150, 1.7),
+        ([(1 << 32) + 10, 1 << 31], 11, 1e-6),
+        ([5000] * 40, 64, 15.0),
+        ([777], 200, 0.0),
+    ]
+    for seed, (lens, fl, cov) in enumerate(cases, start=421):
+        fast, slow = opal_amd.Rng(seed), opal_amd.Rng(seed)
+        pos, gen = fast.sample_positions(lens, fl, cov)
+        want_pos, want_gen = [], []
+        for g, L in enumerate(lens):
+            if L < fl:
+                continue
+            covered, tries = 0, 0
+            while covered < cov * L:
+                tries += 1
+                want_pos.append(slow.randint(0, L - fl))
+                want_gen.append(g)
+                covered += fl
+                if tries > 10 * L:
+                    break
+        assert pos.tolist() == want_pos and gen.tolist() == want_gen
+        assert [fast.randint(0, 10 ** 6) for _ in range(700)] == [slow.randint(0, 10 ** 6) for _ in range(700)]
+        n = len(want_pos)
+        assert fast.shuffle_perm(n + 130).tolist() == _py_shuffle(slow, n + 130)
+
+
+def _py_shuffle(rng, n):
+    x = list(range(n))
+    for i in reversed(range(1, n)):                       # Lib/random.py shuffle
+        j = rng.randint(0, i)
+        x[i], x[j] = x[j], x[i]
+    return x
+
+
 def test_drawfrag_files_match_reference(golden_dir, tmp_path):
     from opal_amd import drawfrag
     for i, c in enumerate(_load(golden_dir, "drawfrag.json")):
