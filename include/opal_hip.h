@@ -103,6 +103,15 @@ int opal_rng_shuffle(opal_rng *rng, uint64_t *perm, uint64_t n);
  * F_j = max(0,len_j-k+1) * P * (reverse?2:1)  (get_all_substrings, util/fasta_functions.py:53-54).          */
 int opal_feature_offsets(opal_ctx *ctx, const uint32_t *d_frag_len, uint64_t n, int reverse, uint64_t *d_out_off);
 
+/* Zero-copy drawfrag.  Replaces `sample = seq[pos:pos+size]` + writing the fragment FASTA (util/drawfrag.py:38-46) for
+ * genomes that are resident in HBM as a fragment batch (d_genome_off / d_genome_len = that batch's d_frag_off /
+ * d_frag_len): fragment i becomes a view of frag_len bases at position d_pos[i] of genome d_genome_idx[i] (the two
+ * arrays opal_sample_positions fills), in the units of that genome (bases if packed, bytes if raw).  A draw that does
+ * not fit inside its genome gets length 0.  The result is used with the genomes' own d_reads / reads_bytes.      */
+int opal_fragment_views(opal_ctx *ctx, const uint64_t *d_genome_off, const uint32_t *d_genome_len, uint64_t n_genomes,
+                        const uint64_t *d_pos, const uint32_t *d_genome_idx, uint64_t n, uint32_t frag_len,
+                        uint64_t *d_frag_off, uint32_t *d_frag_len);
+
 /* Emit mode. Replaces fasta2skm.gen_features + VW's name hashing for a whole batch
  * (util/fasta2skm.py:137-141,78-80; vw parse of the line written at opal.py:366-367,468-469):
  * d_out_idx[d_out_off[i] + f] = hash(name of feature f of fragment i) & (2^bits - 1), features in the

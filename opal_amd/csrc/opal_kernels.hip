@@ -269,6 +269,33 @@ __global__ void mirror_head_kernel(float *w, uint64_t n_slots, uint32_t pad)
     if (i < pad) w[n_slots + i] = w[i % n_slots];
 }
 
+// ------------------------------------------------------------------------------------------ fragment views
+// drawfrag's `seq[pos:pos+l]` (util/drawfrag.py:38-39) without moving a base: fragment i is (offset, length) into the
+// batch that holds the genomes; a draw that does not fit its genome becomes an empty fragment.
+__global__ __launch_bounds__(BLOCK) void fragment_views_kernel(const uint64_t *__restrict__ g_off, const uint32_t *__restrict__ g_len,
+                                                                uint64_t n_genomes, const uint64_t *__restrict__ pos,
+                                                                const uint32_t *__restrict__ gen, uint64_t n, uint32_t frag_len,
+                                                                uint64_t *__restrict__ frag_off, uint32_t *__restrict__ out_len)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        const uint32_t g = gen[i];
+        const uint64_t p = pos[i];
+        uint64_t o = 0;
+        uint32_t lw = 0;
+        if (g < n_genomes) {
+            const uint32_t glw = g_len[g];
+            const uint64_t gl = glw & ~OPAL_RAW_FLAG;
+            if (p <= gl && frag_len <= gl - p) {
+                o = g_off[g] + p;                               // bases for packed genomes, bytes for raw ones
+                lw = (glw & OPAL_RAW_FLAG) | frag_len;
+            }
+        }
+        frag_off[i] = o;
+        out_len[i] = lw;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ launch helpers
 struct Variant {
     int vec, nv, u;
@@ -486,6 +513,24 @@ extern "C" int opal_feature_offsets(opal_ctx *ctx, const uint32_t *d_frag_len, u
                            ctx->P, strands, ctx->d_block_sums, d_out_off);
         OPAL_HIP_CHECK(ctx, hipGetLastError());
     }
+    return OPAL_OK;
+}
+
+extern "C" int opal_fragment_views(opal_ctx *ctx, const uint64_t *d_genome_off, const uint32_t *d_genome_len, uint64_t n_genomes,
+                                   const uint64_t *d_pos, const uint32_t *d_genome_idx, uint64_t n, uint32_t frag_len,
+                                   uint64_t *d_frag_off, uint32_t *d_frag_len)
+{
+    if (!ctx) return opal::fail(nullptr, OPAL_EINVAL, "opal_fragment_views: null ctx");
+    if (frag_len >= OPAL_RAW_FLAG) return opal::fail(ctx, OPAL_EINVAL, "opal_fragment_views: need frag_len < 2^31");
+    if (n == 0) return OPAL_OK;
+    if (!d_genome_off || !d_genome_len || !d_pos || !d_genome_idx || !d_frag_off || !d_frag_len)
+        return opal::fail(ctx, OPAL_EINVAL, "opal_fragment_views: null pointer");
+    if (n > (1ull << 40)) return opal::fail(ctx, OPAL_EINVAL, "opal_fragment_views: n too large");
+    OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((n + BLOCK - 1) / BLOCK, (uint64_t)ctx->num_cus * 16));
+    hipLaunchKernelGGL(fragment_views_kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_genome_off, d_genome_len, n_genomes, d_pos,
+                       d_genome_idx, n, frag_len, d_frag_off, d_frag_len);
+    OPAL_HIP_CHECK(ctx, hipGetLastError());
     return OPAL_OK;
 }
 

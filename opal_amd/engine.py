@@ -163,14 +163,22 @@ class GenomeSet:
         return GenomeSet(engine, PackedReads(None, off, ln), dev)
 
     def fragments(self, pos, gen, frag_len: int) -> "DeviceBatch":
-        """pos, gen: arrays from Rng.sample_positions (position inside the genome, genome index)."""
+        """pos, gen: arrays from Rng.sample_positions (position inside the genome, genome index).  The views are built
+        on the device (opal_fragment_views) from the 12 bytes per fragment the sampler produced."""
         t = self.engine.torch
-        gen = np.asarray(gen, dtype=np.int64)
-        off = self.host.off[gen] + np.asarray(pos, dtype=np.uint64)      # bases for packed genomes, bytes for raw ones
-        ln = (self.host.len[gen] & np.uint32(_lib.RAW_FLAG)) | np.uint32(frag_len)
-        d_off = t.from_numpy(np.ascontiguousarray(off).view(np.int64)).to(self.engine.device)
-        d_len = t.from_numpy(np.ascontiguousarray(ln).view(np.int32)).to(self.engine.device)
-        return DeviceBatch(self.dev.data, d_off, d_len, int(len(off)), self.dev.nbytes)
+        dev = self.engine.device
+        pos = np.ascontiguousarray(pos, dtype=np.uint64)
+        gen = np.ascontiguousarray(gen, dtype=np.uint32)
+        n = int(len(pos))
+        assert len(gen) == n
+        d_pos = t.from_numpy(pos.view(np.int64)).to(dev)
+        d_gen = t.from_numpy(gen.view(np.int32)).to(dev)
+        d_off = t.empty(max(n, 1), dtype=t.int64, device=dev)
+        d_len = t.empty(max(n, 1), dtype=t.int32, device=dev)
+        check(lib().opal_fragment_views(self.engine._h, self.dev.off.data_ptr(), self.dev.len.data_ptr(), self.dev.n,
+                                        d_pos.data_ptr(), d_gen.data_ptr(), n, int(frag_len), d_off.data_ptr(), d_len.data_ptr()),
+              self.engine._h)
+        return DeviceBatch(self.dev.data, d_off, d_len, n, self.dev.nbytes)
 
 
 class Engine:
