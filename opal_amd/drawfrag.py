@@ -9,7 +9,7 @@ from .engine import Rng
 from .fasta_functions import check_acgt, fasta_reader
 
 __version__ = "0.0.2"
-__all__ = ["main", "main_not_commandline", "sample_fragments"]
+__all__ = ["main", "main_not_commandline", "sample_fragments", "write_fragment_files"]
 
 
 def sample_fragments(records, taxid_lines, size, coverage, seed, atgc=False, rng=None):
@@ -45,11 +45,62 @@ def sample_fragments(records, taxid_lines, size, coverage, seed, atgc=False, rng
     return frags, labels
 
 
+def _fasta_block(first_num, frags):
+    """Bytes of `>{n}\n{fragment}\n` for the rows of frags (uint8 [m, size]) numbered first_num, first_num+1, ...:
+    one fixed-width byte matrix per run of numbers with the same digit count."""
+    import numpy as np
+    m, size = frags.shape
+    parts, done = [], 0
+    while done < m:
+        n0 = first_num + done
+        w = len(str(n0))
+        cnt = min(m - done, 10 ** w - n0)                 # numbers that still have w digits
+        block = np.empty((cnt, w + size + 3), dtype=np.uint8)
+        block[:, 0] = ord(">")
+        nums = np.arange(n0, n0 + cnt, dtype=np.int64)
+        for d in range(w):
+            block[:, w - d] = ord("0") + (nums // 10 ** d) % 10
+        block[:, w + 1] = ord("\n")
+        block[:, w + 2:w + 2 + size] = frags[done:done + cnt]
+        block[:, w + 2 + size] = ord("\n")
+        parts.append(block.tobytes())
+        done += cnt
+    return b"".join(parts)
+
+
+def write_fragment_files(records, taxid_lines, size, coverage, seed, out_path, g2t_path, rng=None, chunk=1 << 20):
+    """The two files drawfrag.py:44-47 writes, byte for byte, without a Python loop over fragments: positions from the
+    CPython-exact sampler, fragment text gathered per record with numpy.  Returns the number of fragments."""
+    import numpy as np
+    rng = rng or Rng()
+    if seed:
+        rng.seed(seed)
+    pos, gen = rng.sample_positions([len(s) for _, s in records], size, coverage)
+    ar = np.arange(size, dtype=np.int64)
+    bounds = np.flatnonzero(np.diff(gen.astype(np.int64), prepend=-1, append=-1))   # runs of equal genome index
+    num = 1
+    with open(out_path, "wb") as out, open(g2t_path, "wb") as g2t:
+        for a, b in zip(bounds[:-1].tolist(), bounds[1:].tolist()):
+            g = int(gen[a])
+            name, seq = records[g]
+            arr = np.frombuffer(seq.encode("latin-1"), dtype=np.uint8)
+            for s in range(a, b, chunk):
+                p = pos[s:min(b, s + chunk)].astype(np.int64)
+                out.write(_fasta_block(num, arr[p[:, None] + ar[None, :]]))
+                num += len(p)
+            line = "%s\t%s\n" % (name.split()[0], taxid_lines[g] if g < len(taxid_lines) else "")
+            g2t.write(line.encode("latin-1") * (b - a))
+    return num - 1
+
+
 def main_not_commandline(args):
     with open(args.input, "r", encoding="latin-1") as f:
         records = list(fasta_reader(f))
     with open(args.taxids, "r") as f:
         taxid_lines = [l.rstrip("\n") for l in f]
+    if not args.atgc and args.size > 0:
+        write_fragment_files(records, taxid_lines, args.size, args.coverage, args.seed, args.output, args.gi2taxid)
+        return
     frags, labels = sample_fragments(records, taxid_lines, args.size, args.coverage, args.seed, args.atgc)
     with open(args.output, "w", encoding="latin-1") as out, open(args.gi2taxid, "w", encoding="latin-1") as g2t:
         out.write("".join(">%d\n%s\n" % (i + 1, s) for i, s in enumerate(frags)))

@@ -105,6 +105,28 @@ def test_drawfrag_files_match_reference(golden_dir, tmp_path):
         assert og.read_text() == c["out_gi2taxid"]
 
 
+def test_vectorised_fragment_writer_equals_per_fragment_loop(tmp_path):
+    """write_fragment_files (numpy gather, fixed-width header blocks) writes the bytes the reference's per-fragment
+    loop writes (drawfrag.py:44-47): across the 9->10, 99->100, 999->1000 header widths, with records shorter than the
+    fragment, lower case / N / latin-1 bytes in the text, names with spaces, a missing taxid line."""
+    import opal_amd
+    from opal_amd import drawfrag
+    rng = np.random.default_rng(5)
+    recs = []
+    for i, L in enumerate([700, 30, 2500, 64, 65, 9000, 1200]):
+        seq = "".join(rng.choice(list("ACGTacgtN\xe9"), size=L))
+        recs.append(("rec%d some description" % i, seq))
+    taxids = ["t%d" % i for i in range(len(recs) - 1)]                 # the last record has no taxid line
+    for size, cov, seed in ((64, 9.0, 42), (65, 0.5, 421), (1, 0.2, 7)):
+        frags, labels = drawfrag.sample_fragments(recs, taxids, size, cov, seed)
+        want_f = "".join(">%d\n%s\n" % (i + 1, s) for i, s in enumerate(frags)).encode("latin-1")
+        want_g = "".join("%s\t%s\n" % nl for nl in labels).encode("latin-1")
+        n = drawfrag.write_fragment_files(recs, taxids, size, cov, seed, str(tmp_path / "f.fasta"), str(tmp_path / "g.txt"), chunk=100)
+        assert n == len(frags) and (size != 64 or n > 1000)
+        assert (tmp_path / "f.fasta").read_bytes() == want_f
+        assert (tmp_path / "g.txt").read_bytes() == want_g
+
+
 def test_ldpc_files_match_reference(golden_dir, tmp_path):
     from opal_amd import ldpc
     for fname, m in _load(golden_dir, "patterns_meta.json").items():
