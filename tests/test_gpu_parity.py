@@ -397,6 +397,20 @@ def test_gpu_fasta_ingest_matches_reference_reader(amd, eng, oracle, golden_dir)
     rc = lib().opal_ingest_fasta(eng._h, d_text.data_ptr(), len(big), reads.data_ptr(), len(big) * 2, off.data_ptr(), ln.data_ptr(), 100,
                                  C.byref(nrec), C.byref(nb))
     assert rc == OPAL_ERANGE
+    # a text pointer that is not 16-byte aligned (every thread then loads byte by byte), an unaligned output pointer
+    shifted = torch.empty(len(big) + 16, dtype=torch.uint8, device=eng.device)
+    for sh in (1, 7):
+        shifted[sh:sh + len(big)] = d_text
+        reads = torch.zeros(len(big) * 2, dtype=torch.uint8, device=eng.device)
+        rc = lib().opal_ingest_fasta(eng._h, shifted.data_ptr() + sh, len(big), reads.data_ptr(), len(big) * 2, off.data_ptr(),
+                                     ln.data_ptr(), max_rec, C.byref(nrec), C.byref(nb))
+        assert rc == 0 and nrec.value == ref.n
+        got = amd.PackedReads(reads.cpu().numpy()[:nb.value], off.cpu().numpy()[:ref.n].view(np.uint64),
+                              ln.cpu().numpy()[:ref.n].view(np.uint32))
+        assert got.sequences() == [sq for _, sq in oracle.fasta_read(big, universal_newlines=True)]
+    from opal_amd._lib import OPAL_EINVAL
+    assert lib().opal_ingest_fasta(eng._h, d_text.data_ptr(), len(big), reads.data_ptr() + 2, len(big), off.data_ptr(), ln.data_ptr(),
+                                   max_rec, C.byref(nrec), C.byref(nb)) == OPAL_EINVAL
     # end to end: predictions from the ingested batch equal predictions from host-parsed records
     pos = _patterns(amd, golden_dir, "patterns_k64_t16_m1_s7.txt", 64)
     eng.set_patterns(pos, 64)
