@@ -45,6 +45,9 @@ WORKLOADS = {
     "train_356sp_warm": dict(K=356, n=200_000, pattern="patterns_k64_t16_m1_s7.txt", bits=31, mode="train", cold=False,
                              desc="native OAA learner, later passes over the same 200k fragments: classes already at their "
                                   "label after the clip are skipped, 356 classes, numHash=1, -r, b=31"),
+    "ingest_reads": dict(K=1, n=4_000_000, pattern="patterns_k64_t16_m1_s7.txt", bits=18, mode="ingest",
+                         desc="GPU FASTA ingest (SURVEY.md 8f-3): 4M records of 200 bp as FASTA text resident in HBM -> "
+                              "2-bit packed fragment batch (opal_ingest_scan + opal_ingest_fasta)"),
     "train_1564sp": dict(K=1564, n=50_000, pattern="patterns_k64_t16_m1_s7.txt", bits=31, mode="train", cold=True,
                          desc="native OAA learner, worst case (zeroed table each step): 50k labelled 200bp fragments, 1564 classes"),
 }
@@ -81,6 +84,8 @@ def make_fragments(rank, n, L, K):
 def algorithmic_bytes_per_fragment(L, F, K, mode):
     if mode == "emit":
         return math.ceil(L / 4) + 4 * F                      # 2-bit read + one u32 per feature
+    if mode == "ingest":
+        return (1 + 8 + 1 + L + 1) + math.ceil(L / 4) + 12   # the record's text once + its packed bases + (offset, length)
     if mode == "train":
         # sweep 1 reads w rows; sweep 2 reads+writes G rows; sweep 3 reads G rows, reads+writes w rows (opal_train.hip)
         return math.ceil(L / 4) + 6 * 4 * K * (F + 1) + 4
@@ -153,6 +158,22 @@ def main():
     if mode == "predict":
         codes = make_fragments(rank, n, L, max(K, 1))
         batch = eng.upload(opal_amd.PackedReads.from_codes(codes))
+    elif mode == "ingest":
+        # ">%08d\n" + 200 bases + "\n" per record, uniform ACGT (PCG64 seed 1234 + rank)
+        codes = None
+        rec = np.empty((n, 10 + L + 1), dtype=np.uint8)
+        rec[:, 0] = ord(">")
+        ids = np.arange(n)
+        for d in range(8):
+            rec[:, 8 - d] = ord("0") + (ids // 10 ** d) % 10
+        rec[:, 9] = rec[:, 10 + L] = ord("\n")
+        rec[:, 10:10 + L] = np.frombuffer(b"ACGT", dtype=np.uint8)[
+            np.random.Generator(np.random.PCG64(1234 + rank)).integers(0, 4, size=(n, L), dtype=np.uint8)]
+        d_text = torch.from_numpy(rec.reshape(-1)).to(dev)
+        nbytes = int(d_text.numel())
+        ing_reads = torch.empty(nbytes // 4 + 4096, dtype=torch.uint8, device=dev)
+        ing_off = torch.empty(n, dtype=torch.int64, device=dev)
+        ing_len = torch.empty(n, dtype=torch.int32, device=dev)
     else:
         # genomes packed once and resident in HBM; a batch is 12 bytes of (offset, length) per fragment
         g, gpos, ggen = make_genomes_and_draws(rank, n, L, max(K, 1), 200_000)
@@ -170,6 +191,16 @@ def main():
 
         def step():
             eng.train_batch(batch, labels, True, eta=0.5)
+    elif mode == "ingest":
+        import ctypes as C
+        from opal_amd._lib import check, lib
+        c_a, c_b = C.c_uint64(), C.c_uint64()
+
+        def step():
+            check(lib().opal_ingest_scan(eng._h, d_text.data_ptr(), nbytes, C.byref(c_a), C.byref(c_b)), eng._h)
+            check(lib().opal_ingest_fasta(eng._h, d_text.data_ptr(), nbytes, ing_reads.data_ptr(), ing_reads.numel(), ing_off.data_ptr(),
+                                          ing_len.data_ptr(), n, C.byref(c_a), C.byref(c_b)), eng._h)
+            assert c_a.value == n
     elif mode == "emit":
         offsets = eng.feature_offsets(batch, True)
         total = int(offsets[-1].item())
@@ -227,12 +258,13 @@ def main():
         res = {
             "metric": "fragments/sec", "value": frag_per_s, "unit": "fragments/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32" if mode == "emit" else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u8" if mode == "ingest" else "u32" if mode == "emit" else "f32", "data": "synthetic",
             "config": {"workload": args.workload, "desc": wl["desc"], "classes": K, "fragments_per_gpu": n, "frag_len": L,
                        "kmer": k, "row_weight": 16, "patterns": P, "reverse_complement": True, "bits": bits,
                        "features_per_fragment": F, "parallelism": "fragment-sharded x%d, replicated table, no collective" % world},
-            "hashes_per_s": frag_per_s * F,
-            "kernel": {"predict": eng.predict_kernel_name(), "emit": "emit_idx_kernel", "train": "train_kernel"}[mode],
+            "hashes_per_s": None if mode == "ingest" else frag_per_s * F,
+            "kernel": {"predict": eng.predict_kernel_name(), "emit": "emit_idx_kernel", "train": "train_kernel",
+                       "ingest": "ing_summary_kernel + ing_scan_kernel + ing_pack_kernel + ing_records_kernel (whole call)"}[mode],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": abytes, "kernel_ms": kern_ms},
