@@ -13,7 +13,8 @@
 // event (sequence iff the record it continues is unmuted), cC = bytes that are sequence whatever came before.
 // Summaries compose associatively, which gives two passes over the text:
 //   1. ing_summary_kernel   one summary per 16 KiB tile (text read once)
-//   2. ing_scan_kernel      one block scans the tile summaries into the state and sequence position each tile starts at
+//   2. ing_scan_local_kernel + ing_scan_kernel   two-level scan of the tile summaries (inside segments of 256 tiles, then
+//                           one block over the segment totals) -> the state and sequence position each tile starts at
 //   3. ing_pack_kernel      text read again: every sequence byte now knows its position in the concatenated sequence;
 //                           its 2-bit code goes straight into ONE packed stream of all sequence bytes (LDS-staged,
 //                           whole dwords stored), headers record where their sequence starts, bytes outside ACGT
@@ -284,13 +285,30 @@ __global__ __launch_bounds__(BLOCK) void ing_summary_kernel(const uint8_t *__res
     }
 }
 
-// ---- pass 2: the state every tile starts in ----------------------------------------------------------------------
+// ---- pass 2a: scan of the tile summaries inside segments of 256 tiles (one block each, one tile per thread) -----------
+constexpr int SEG_TILES = BLOCK;
+__global__ __launch_bounds__(BLOCK) void ing_scan_local_kernel(const Sum *__restrict__ tile_sum, uint64_t ntiles, Sum *__restrict__ tile_excl,
+                                                                Sum *__restrict__ seg_sum)
+{
+    __shared__ Sum s_w[WPB];
+    const uint64_t i = (uint64_t)blockIdx.x * SEG_TILES + threadIdx.x;
+    const Sum v = i < ntiles ? tile_sum[i] : sum_identity();
+    Sum total;
+    const Sum excl = block_excl_scan_sum(v, s_w, total);
+    if (i < ntiles) tile_excl[i] = excl;                   // what the segment holds in front of tile i
+    if (threadIdx.x == 0) seg_sum[blockIdx.x] = total;
+}
+
+// ---- pass 2b: the state every segment starts in (one block over the segment totals) ----------------------------------------------------------------------
 // fin: [0] headers in the text, [1] sequence bytes T, [2] cursor of the raw area (starts behind the packed stream),
 //      [3] raw records, [4] a record is longer than 2^31-1, [5] the last record is empty (dropped), [6] raw area overflow
 enum { F_H = 0, F_T, F_CURSOR, F_NRAW, F_TOOLONG, F_DROPPED, F_OVERFLOW, F_WORDS = 8 };
-constexpr int SC_ITEMS = 8;
-constexpr int SC_WAVES = 16;                       // one block of 1024 threads: the scan is a chain of short rounds
+constexpr int SC_ITEMS = 2;
+constexpr int SC_WAVES = 4;
 constexpr int SC_BLOCK = SC_WAVES * WAVE;
+// a round covers SC_BLOCK * SC_ITEMS segments of SEG_TILES tiles = 2 GiB of text: the u32 counts of a Sum hold
+static_assert((uint64_t)SC_BLOCK * SC_ITEMS * SEG_TILES * ING_TILE <= (1ull << 31), "u32 counts inside one scan round");
+// (written for any list of summaries: here tile_sum / ntiles / tile_pre are the segment totals, their count, the segment states)
 __global__ __launch_bounds__(SC_BLOCK) void ing_scan_kernel(const Sum *__restrict__ tile_sum, uint64_t ntiles, Pre *__restrict__ tile_pre,
                                                           uint64_t *__restrict__ fin)
 {
@@ -298,7 +316,7 @@ __global__ __launch_bounds__(SC_BLOCK) void ing_scan_kernel(const Sum *__restric
     __shared__ Pre s_carry;
     if (threadIdx.x == 0) s_carry = Pre{0, 0, 0, 0};
     __syncthreads();
-    for (uint64_t b0 = 0; b0 < ntiles; b0 += (uint64_t)SC_BLOCK * SC_ITEMS) {   // 8192 tiles = 128 MiB of text: u32 counts hold
+    for (uint64_t b0 = 0; b0 < ntiles; b0 += (uint64_t)SC_BLOCK * SC_ITEMS) {
         const uint64_t i0 = b0 + (uint64_t)threadIdx.x * SC_ITEMS;
         Sum v[SC_ITEMS], agg = sum_identity();
 #pragma unroll
@@ -348,7 +366,8 @@ __device__ __forceinline__ uint32_t squeeze_fields(uint32_t v, uint32_t keep)
 // raw_flag[r] for every record that holds a byte outside ACGT.
 // RAWCOPY=true: the bytes of the records flagged raw to out8[frag_off[r] + i].
 template <bool RAWCOPY>
-__global__ __launch_bounds__(BLOCK) void ing_pack_kernel(const uint8_t *__restrict__ text, uint64_t n, const Pre *__restrict__ tile_pre,
+__global__ __launch_bounds__(BLOCK) void ing_pack_kernel(const uint8_t *__restrict__ text, uint64_t n, const Pre *__restrict__ seg_pre,
+                                                          const Sum *__restrict__ tile_excl,
                                                           uint64_t *__restrict__ fin, uint32_t *__restrict__ out32, uint64_t cap_words,
                                                           uint64_t *__restrict__ seq_start, uint32_t *__restrict__ raw_flag,
                                                           uint64_t max_records, uint8_t *__restrict__ out8, uint64_t reads_cap,
@@ -364,7 +383,7 @@ __global__ __launch_bounds__(BLOCK) void ing_pack_kernel(const uint8_t *__restri
     const Sum mine = analyse_thread(text, n, base, x, m);
     Sum total;
     const Sum excl = block_excl_scan_sum(mine, s_w, total);
-    const Pre tp = tile_pre[blockIdx.x];
+    const Pre tp = pre_apply(seg_pre[blockIdx.x / SEG_TILES], tile_excl[blockIdx.x]);   // the state this tile starts in
     const Pre in = pre_apply(tp, excl);
     const bool open = in.ev != 2u, open_a = open && in.kind == 3u;
     const uint64_t H = fin[F_H];
@@ -497,17 +516,37 @@ int grow(opal_ctx *ctx, void **p, uint64_t *cap, uint64_t need)
 
 }  // namespace
 
+// scratch of passes 1-2 inside ctx->ing_tiles: [segment states | fin | per-tile prefixes | tile summaries | segment totals]
+struct IngScratch {
+    Pre *seg_pre;
+    uint64_t *fin;
+    Sum *tile_excl, *tile_sum, *seg_sum;
+    uint64_t nseg, bytes;
+};
+static IngScratch ing_layout(void *base, uint64_t ntiles)
+{
+    IngScratch L;
+    L.nseg = (ntiles + SEG_TILES - 1) / SEG_TILES;
+    L.seg_pre = (Pre *)base;                                   // 24-byte entries, 8-byte aligned
+    L.fin = (uint64_t *)(L.seg_pre + L.nseg);
+    L.tile_excl = (Sum *)(L.fin + F_WORDS);
+    L.tile_sum = L.tile_excl + ntiles;
+    L.seg_sum = L.tile_sum + ntiles;
+    L.bytes = L.nseg * (sizeof(Pre) + sizeof(Sum)) + F_WORDS * sizeof(uint64_t) + 2 * ntiles * sizeof(Sum) + 256;
+    return L;
+}
+
 // passes 1-2: tile summaries and the state every tile starts in; fin[F_H], fin[F_T], fin[F_CURSOR] are set
 static int ingest_scan_passes(opal_ctx *ctx, const uint8_t *d_text, uint64_t nbytes, uint64_t ntiles)
 {
-    int rc = grow(ctx, &ctx->ing_tiles, &ctx->ing_tiles_cap, ntiles * (sizeof(Sum) + sizeof(Pre)) + F_WORDS * sizeof(uint64_t) + 256);
+    const IngScratch S = ing_layout(nullptr, ntiles);
+    int rc = grow(ctx, &ctx->ing_tiles, &ctx->ing_tiles_cap, S.bytes);
     if (rc) return rc;
-    Pre *tile_pre = (Pre *)ctx->ing_tiles;                       // 24-byte entries, 8-byte aligned
-    uint64_t *fin = (uint64_t *)(tile_pre + ntiles);
-    Sum *tile_sum = (Sum *)(fin + F_WORDS);
-    OPAL_HIP_CHECK(ctx, hipMemsetAsync(fin, 0, F_WORDS * sizeof(uint64_t), ctx->stream));
-    hipLaunchKernelGGL(ing_summary_kernel, dim3((unsigned)ntiles), dim3(BLOCK), 0, ctx->stream, d_text, nbytes, tile_sum);
-    hipLaunchKernelGGL(ing_scan_kernel, dim3(1), dim3(SC_BLOCK), 0, ctx->stream, tile_sum, ntiles, tile_pre, fin);
+    const IngScratch L = ing_layout(ctx->ing_tiles, ntiles);
+    OPAL_HIP_CHECK(ctx, hipMemsetAsync(L.fin, 0, F_WORDS * sizeof(uint64_t), ctx->stream));
+    hipLaunchKernelGGL(ing_summary_kernel, dim3((unsigned)ntiles), dim3(BLOCK), 0, ctx->stream, d_text, nbytes, L.tile_sum);
+    hipLaunchKernelGGL(ing_scan_local_kernel, dim3((unsigned)L.nseg), dim3(BLOCK), 0, ctx->stream, L.tile_sum, ntiles, L.tile_excl, L.seg_sum);
+    hipLaunchKernelGGL(ing_scan_kernel, dim3(1), dim3(SC_BLOCK), 0, ctx->stream, L.seg_sum, L.nseg, L.seg_pre, L.fin);
     OPAL_HIP_CHECK(ctx, hipGetLastError());
     return OPAL_OK;
 }
@@ -527,7 +566,7 @@ extern "C" int opal_ingest_scan(opal_ctx *ctx, const uint8_t *d_text, uint64_t n
     int rc = ingest_scan_passes(ctx, d_text, nbytes, ntiles);
     if (rc) return rc;
     uint64_t host[2];
-    OPAL_HIP_CHECK(ctx, hipMemcpyAsync(host, (uint64_t *)((Pre *)ctx->ing_tiles + ntiles), sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+    OPAL_HIP_CHECK(ctx, hipMemcpyAsync(host, ing_layout(ctx->ing_tiles, ntiles).fin, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
     OPAL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     *n_headers_out = host[F_H];
     *seq_bytes_out = host[F_T];
@@ -562,8 +601,8 @@ extern "C" int opal_ingest_fasta(opal_ctx *ctx, const uint8_t *d_text, uint64_t 
         rc = ingest_scan_passes(ctx, d_text, nbytes, ntiles);
         if (rc) return rc;
     }
-    Pre *tile_pre = (Pre *)ctx->ing_tiles;
-    uint64_t *fin = (uint64_t *)(tile_pre + ntiles);
+    const IngScratch L = ing_layout(ctx->ing_tiles, ntiles);
+    uint64_t *fin = L.fin;
     uint64_t *seq_start = (uint64_t *)ctx->ing_rec;
     uint32_t *raw_flag = (uint32_t *)(seq_start + (max_records + 1));
     uint32_t *out32 = reinterpret_cast<uint32_t *>(d_reads_out);
@@ -573,7 +612,7 @@ extern "C" int opal_ingest_fasta(opal_ctx *ctx, const uint8_t *d_text, uint64_t 
     OPAL_HIP_CHECK(ctx, hipMemsetAsync(out32, 0, zero_words * 4, st));
     OPAL_HIP_CHECK(ctx, hipMemsetAsync(seq_start, 0, sizeof(uint64_t), st));   // a file without any '>' is one record that starts at 0
     OPAL_HIP_CHECK(ctx, hipMemsetAsync(raw_flag, 0, max_records * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(ing_pack_kernel<false>, dim3((unsigned)ntiles), dim3(BLOCK), 0, st, d_text, nbytes, tile_pre, fin, out32, cap_words,
+    hipLaunchKernelGGL(ing_pack_kernel<false>, dim3((unsigned)ntiles), dim3(BLOCK), 0, st, d_text, nbytes, L.seg_pre, L.tile_excl, fin, out32, cap_words,
                        seq_start, raw_flag, max_records, d_reads_out, reads_cap, d_frag_off);
     const int rgrid = (int)std::max<uint64_t>(1, std::min<uint64_t>((max_records + BLOCK - 1) / BLOCK, (uint64_t)ctx->num_cus * 8));
     hipLaunchKernelGGL(ing_records_kernel, dim3(rgrid), dim3(BLOCK), 0, st, seq_start, raw_flag, fin, max_records, reads_cap, d_frag_off,
@@ -591,7 +630,7 @@ extern "C" int opal_ingest_fasta(opal_ctx *ctx, const uint8_t *d_text, uint64_t 
     const uint64_t out_bytes = host[F_NRAW] ? host[F_CURSOR] : ((T + 3) / 4 + 3) & ~3ull;
     if (out_bytes > reads_cap || host[F_OVERFLOW]) return opal::fail(ctx, OPAL_ERANGE, "opal_ingest_fasta: d_reads_out too small");
     if (host[F_NRAW]) {
-        hipLaunchKernelGGL(ing_pack_kernel<true>, dim3((unsigned)ntiles), dim3(BLOCK), 0, st, d_text, nbytes, tile_pre, fin, out32, cap_words,
+        hipLaunchKernelGGL(ing_pack_kernel<true>, dim3((unsigned)ntiles), dim3(BLOCK), 0, st, d_text, nbytes, L.seg_pre, L.tile_excl, fin, out32, cap_words,
                            seq_start, raw_flag, max_records, d_reads_out, reads_cap, d_frag_off);
         OPAL_HIP_CHECK(ctx, hipGetLastError());
         OPAL_HIP_CHECK(ctx, hipStreamSynchronize(st));
