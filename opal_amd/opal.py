@@ -355,29 +355,37 @@ def fasta_pieces(path, chunk_bytes):
         start = cut
 
 
-def _prefetched(gen, depth=1):
-    """Runs a generator in a background thread, `depth` items ahead: the next piece is read from disk while the GPU
-    scores the current one."""
-    import queue
-    import threading
-    q, done = queue.Queue(maxsize=depth), object()
+class _Prefetched:
+    """Runs a generator in a background thread, `depth` items ahead, starting at once: the file is being read while the
+    GPU context and the model are set up, and the next piece is read while the GPU scores the current one."""
 
-    def work():
-        try:
-            for item in gen:
-                q.put(item)
-            q.put(done)
-        except BaseException as e:      # hand the error to the consumer
-            q.put(e)
+    _DONE = object()
 
-    threading.Thread(target=work, daemon=True).start()
-    while True:
-        item = q.get()
-        if item is done:
-            return
+    def __init__(self, gen, depth=1):
+        import queue
+        import threading
+        self._q = queue.Queue(maxsize=depth)
+
+        def work():
+            try:
+                for item in gen:
+                    self._q.put(item)
+                self._q.put(self._DONE)
+            except BaseException as e:      # hand the error to the consumer
+                self._q.put(e)
+
+        threading.Thread(target=work, daemon=True).start()
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item = self._q.get()
+        if item is self._DONE:
+            raise StopIteration
         if isinstance(item, BaseException):
             raise item
-        yield item
+        return item
 
 
 # ------------------------------------------------------------------ predict (reference opal.py:392-493)
@@ -403,6 +411,11 @@ def predict(model_dir, test_dir, predict_dir, args, engine=None, chunk_bytes=Non
     prefix = os.path.join(predict_dir, "test.fragments-db")
     prediction_file = prefix + ".preds.vw"
 
+    # the file's bytes go to HBM as they are, a piece of about 1 GiB at a time (read by a background thread that starts
+    # now, before the GPU context exists); records are split and 2-bit packed on the device (opal_ingest_fasta)
+    if chunk_bytes is None:
+        chunk_bytes = int(os.environ.get("OPAL_PREDICT_CHUNK_BYTES", str(1 << 30)))
+    pieces = _Prefetched(fasta_pieces(fasta, chunk_bytes))
     with open(pattern_file, "r") as f:
         pos = parse_patterns(f.readlines(), kmer)
     eng = engine or Engine(local)
@@ -413,13 +426,10 @@ def predict(model_dir, test_dir, predict_dir, args, engine=None, chunk_bytes=Non
                                 reverse=reverse)
         with open(args.dump_vw_text, "w", encoding="latin-1") as f:
             f.writelines(fasta2skm.main_generator(ns, engine=eng))
-    # the file's bytes go to HBM as they are, a piece of a few GiB at a time; records are split and 2-bit packed on the
-    # device (opal_ingest_fasta); every rank scores a contiguous range of each piece's fragments
+    # every rank scores a contiguous range of each piece's fragments
     from .engine import DeviceBatch
-    if chunk_bytes is None:
-        chunk_bytes = int(os.environ.get("OPAL_PREDICT_CHUNK_BYTES", str(8 << 30)))
     parts, n_frag = [], 0
-    for piece in _prefetched(fasta_pieces(fasta, chunk_bytes)):
+    for piece in pieces:
         whole = eng.ingest_fasta(piece)
         n_frag += whole.n
         lo, hi = shard_range(whole.n, rank, world)
