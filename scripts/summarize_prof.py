@@ -41,6 +41,21 @@ def main(out):
         if vals:
             res[ctr + "_KiB_per_launch"] = sum(vals) / len(vals)
             res[ctr + "_launches"] = len(vals)
+    if not hot and any("ing_summary_kernel" in n for n in stats):
+        # FASTA ingest: several kernels per call; counters are summed over them and divided by the number of calls
+        res["kernel"] = "ing_summary_kernel + ing_scan_local_kernel + ing_scan_kernel + ing_pack_kernel + ing_records_kernel"
+        calls = int(next(r for n, r in stats.items() if "ing_summary_kernel" in n)["Calls"])
+        res["calls"] = calls
+        res["avg_kernel_ms"] = sum(float(r["TotalDurationNs"]) for n, r in stats.items() if "::ing_" in n) / calls / 1e6
+        for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+            tot, launches = 0.0, 0
+            for r in rows(os.path.join(out, sub, "**", "*counter_collection.csv")):
+                if r.get("Counter_Name") == ctr and "::ing_" in r["Kernel_Name"]:
+                    tot += float(r["Counter_Value"])
+                    launches += "ing_summary_kernel" in r["Kernel_Name"]
+            if launches:
+                res[ctr + "_KiB_per_launch"] = tot / launches
+                res[ctr + "_launches"] = launches
     if "FETCH_SIZE_KiB_per_launch" in res:
         rd = res["FETCH_SIZE_KiB_per_launch"] * 1024 * 2   # gfx950: wide coalesced reads are tallied at half
         wr = res.get("WRITE_SIZE_KiB_per_launch", 0.0) * 1024
