@@ -20,7 +20,7 @@ import numpy as np
 from . import drawfrag, fasta2skm, ldpc
 from . import model as model_io
 from .engine import Engine, GenomeSet, Rng, parse_patterns
-from .shard import gather_in_rank_order, shard_range
+from .shard import gather_in_rank_order
 
 __version__ = "1.0.0"
 
@@ -333,26 +333,50 @@ def _next_header(text, start):
     return size
 
 
-def fasta_pieces(path, chunk_bytes):
+def fasta_pieces(path, chunk_bytes, rank=0, world=1):
     """The file as uint8 arrays of about chunk_bytes each, cut in front of header lines, so that files larger than host
-    or GPU memory stream through predict the way the reference streams lines into vw (opal.py:458-469).  A header
-    resets the reader's state (fasta_functions.py:24-35), so pieces are independent; every piece but the last gets one
-    extra '>' appended: the reader drops an EMPTY LAST record (fasta_functions.py:20-22), which must only happen at
-    the real end of the file, and that sentinel is exactly such a record."""
+    or GPU memory stream through predict the way the reference streams lines into vw (opal.py:458-469).  Piece i is
+    [cut(i*chunk_bytes), cut((i+1)*chunk_bytes)) with cut(x) = start of the first header line at or after x, so every
+    piece can be found without looking at the rest of the file: rank r of `world` yields pieces r, r+world, ... (and an
+    empty array once the file has run out, so that all ranks make the same number of steps) and reads only those.
+    A header resets the reader's state (fasta_functions.py:24-35), so pieces are independent; every piece but the one
+    that ends the file gets one extra '>' appended: the reader drops an EMPTY LAST record (fasta_functions.py:20-22),
+    which must only happen at the real end of the file, and that sentinel is exactly such a record."""
     size = os.path.getsize(path)
-    if size <= chunk_bytes:
-        yield np.fromfile(path, dtype=np.uint8)
+    chunk_bytes = max(1, int(chunk_bytes))
+    n_pieces = max(1, -(-size // chunk_bytes))
+    rounds = -(-n_pieces // world)
+    empty = np.zeros(0, dtype=np.uint8)
+    if n_pieces == 1:
+        yield np.fromfile(path, dtype=np.uint8) if rank == 0 else empty
         return
     text = np.memmap(path, dtype=np.uint8, mode="r")
-    start = 0
-    while start < size:
-        cut = _next_header(text, start + chunk_bytes) if start + chunk_bytes < size else size
-        piece = np.empty(cut - start + (1 if cut < size else 0), dtype=np.uint8)
-        piece[:cut - start] = text[start:cut]
-        if cut < size:
+
+    def cut(x):
+        return 0 if x <= 0 else (size if x >= size else _next_header(text, x))
+
+    for j in range(rounds):
+        i = j * world + rank
+        lo, hi = (cut(i * chunk_bytes), cut((i + 1) * chunk_bytes)) if i < n_pieces else (size, size)
+        if hi <= lo:
+            yield empty
+            continue
+        piece = np.empty(hi - lo + (1 if hi < size else 0), dtype=np.uint8)
+        piece[:hi - lo] = text[lo:hi]
+        if hi < size:
             piece[-1] = 62
         yield piece
-        start = cut
+
+
+def default_chunk_bytes(path, world):
+    """Piece size of predict: 1 GiB (OPAL_PREDICT_CHUNK_BYTES overrides); with several ranks at least four pieces per
+    rank (but no smaller than 16 MiB) so that the ranks stay evenly loaded."""
+    env = os.environ.get("OPAL_PREDICT_CHUNK_BYTES")
+    if env:
+        return int(env)
+    if world <= 1:
+        return 1 << 30
+    return int(min(1 << 30, max(16 << 20, os.path.getsize(path) // (4 * world) + 1)))
 
 
 class _Prefetched:
@@ -414,8 +438,8 @@ def predict(model_dir, test_dir, predict_dir, args, engine=None, chunk_bytes=Non
     # the file's bytes go to HBM as they are, a piece of about 1 GiB at a time (read by a background thread that starts
     # now, before the GPU context exists); records are split and 2-bit packed on the device (opal_ingest_fasta)
     if chunk_bytes is None:
-        chunk_bytes = int(os.environ.get("OPAL_PREDICT_CHUNK_BYTES", str(1 << 30)))
-    pieces = _Prefetched(fasta_pieces(fasta, chunk_bytes))
+        chunk_bytes = default_chunk_bytes(fasta, world)
+    pieces = _Prefetched(fasta_pieces(fasta, chunk_bytes, rank, world))
     with open(pattern_file, "r") as f:
         pos = parse_patterns(f.readlines(), kmer)
     eng = engine or Engine(local)
@@ -426,23 +450,22 @@ def predict(model_dir, test_dir, predict_dir, args, engine=None, chunk_bytes=Non
                                 reverse=reverse)
         with open(args.dump_vw_text, "w", encoding="latin-1") as f:
             f.writelines(fasta2skm.main_generator(ns, engine=eng))
-    # every rank scores a contiguous range of each piece's fragments
-    from .engine import DeviceBatch
+    # every rank scores its own pieces (fragments are independent; no data-path collective); after each
+    # round of pieces the class ids are concatenated on rank 0 in piece order = file order
     parts, n_frag = [], 0
     for piece in pieces:
-        whole = eng.ingest_fasta(piece)
-        n_frag += whole.n
-        lo, hi = shard_range(whole.n, rank, world)
-        if hi > lo:
-            mine = DeviceBatch(whole.data, whole.off[lo:hi], whole.len[lo:hi], hi - lo, whole.nbytes)
-            cls, _ = eng.predict(mine, reverse)
-            local_cls = cls.cpu().numpy()
+        if piece.size:
+            batch = eng.ingest_fasta(piece)
+            cls, _ = eng.predict(batch, reverse)
+            local_cls = cls.cpu().numpy() if batch.n else np.zeros(0, dtype=np.int32)
+            del batch
         else:
             local_cls = np.zeros(0, dtype=np.int32)
         got = gather_in_rank_order(local_cls, dist)
         if rank == 0:
             parts.append(got)
-        del whole, piece
+            n_frag += int(got.shape[0])
+        del piece
     if rank == 0:
         full = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int32)
         with open(prefix + "_vwps.log", "w") as log:

@@ -266,11 +266,12 @@ def _predict_rank(rank, world, port, model_dir, test_dir, out_dir):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from opal_amd import opal
-    opal.predict(model_dir, test_dir, out_dir, argparse.Namespace(kmer=64, reverse_complement=True))
+    # pieces of ~10 kB: the 1001 reads make about 18 pieces, dealt to the ranks in turn
+    opal.predict(model_dir, test_dir, out_dir, argparse.Namespace(kmer=64, reverse_complement=True), chunk_bytes=10_000)
 
 
 def test_cli_predict_two_ranks_equals_one(amd, tmp_path):
-    """`opal.py predict` launched as two ranks (here both on the one GPU of the box): each scores its contiguous shard,
+    """`opal.py predict` launched as two ranks (here both on the one GPU of the box): each scores its own pieces of the file,
     rank 0 writes the files; the result equals the single-process run byte for byte."""
     import argparse
     import socket

@@ -296,3 +296,12 @@ def test_fasta_pieces_preserve_the_reference_readers_records(tmp_path, oracle):
             assert [s for _, s in got] == [s for _, s in want], (ti, chunk)
             if 0 < chunk < len(text) // 4 and b">" in text[1:]:
                 assert n_pieces > 1
+            # the same pieces dealt to 3 ranks: every rank makes the same number of steps, and reading the steps in
+            # (round, rank) order gives the file's records
+            per_rank = [list(opal.fasta_pieces(str(path), chunk, r, 3)) for r in range(3)]
+            assert len({len(x) for x in per_rank}) == 1
+            got3 = []
+            for rnd in range(len(per_rank[0])):
+                for r in range(3):
+                    got3 += oracle.fasta_read(per_rank[r][rnd].tobytes())
+            assert [s for _, s in got3] == [s for _, s in want], (ti, chunk, "3 ranks")
