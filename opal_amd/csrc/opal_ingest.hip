@@ -122,14 +122,18 @@ __device__ __forceinline__ Sum block_excl_scan_sum(const Sum &v, Sum *s_w, Sum &
 }
 
 // ---- 16 bytes at a time ------------------------------------------------------------------------------------------
-// 0x80 in every byte of x that equals the byte replicated in pat (exact for all byte values)
-__device__ __forceinline__ uint32_t eq_flags(uint32_t x, uint32_t pat)
+// The 2-bit fields in bits 0-1 of every byte of f0..f3 (byte b of f_d belongs to text byte 4d+b) as one word in text
+// order: field j in bits 2j, 2j+1.  Or-ing the four words puts field (b,d) at bit 8b+2d; two delta swaps exchange the
+// roles of b and d (a 4x4 transpose of 2-bit fields).
+__device__ __forceinline__ uint32_t gather_fields(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3)
 {
-    const uint32_t t = x ^ pat;
-    return ~((((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) | 0x7f7f7f7fu);
+    uint32_t F = f0 | (f1 << 2) | (f2 << 4) | (f3 << 6);
+    uint32_t t = ((F >> 12) ^ F) & 0x0000f0f0u;       // exchange address bits 4 and 2
+    F ^= t | (t << 12);
+    t = ((F >> 6) ^ F) & 0x00cc00ccu;                  // exchange address bits 3 and 1
+    F ^= t | (t << 6);
+    return F;
 }
-// bits 8b and 8b+1 of f (b = 0..3) -> bits 2b and 2b+1
-__device__ __forceinline__ uint32_t squeeze2(uint32_t f) { return (f | (f >> 6) | (f >> 12) | (f >> 18)) & 0xffu; }
 
 __device__ __forceinline__ uint32_t chunk_byte(const uint32_t (&x)[4], uint32_t j)
 {
@@ -141,16 +145,20 @@ __device__ __forceinline__ uint32_t chunk_byte(const uint32_t (&x)[4], uint32_t 
     return (w >> ((j & 3u) * 8u)) & 0xffu;
 }
 
-// Terminator flags of a chunk: bit 2j = byte j is '\r', bit 2j+1 = byte j is '\n'
+// Terminator flags of a chunk: bit 2j = byte j is '\r', bit 2j+1 = byte j is '\n'.
+// v_perm_b32 with the DATA as selector is an exact one-byte-value test: selector 12 yields 0x00, selectors >= 13 yield
+// 0xff, selectors 0..11 pick a source byte or a source sign (all 0xff here).  x ^ 0x06 sends '\n' (10) and nothing else
+// to 12, x ^ 0x01 sends '\r' (13) and nothing else to 12.
 __device__ __forceinline__ uint32_t term_fields(const uint32_t (&x)[4])
 {
-    uint32_t I = 0;
+    uint32_t f[4];
 #pragma unroll
     for (int d = 0; d < 4; d++) {
-        const uint32_t m = eq_flags(x[d], 0x0a0a0a0au) | (eq_flags(x[d], 0x0d0d0d0du) >> 1);
-        I |= squeeze2(m >> 6) << (8 * d);
+        const uint32_t not_nl = __builtin_amdgcn_perm(0xffffffffu, 0xffffffffu, x[d] ^ 0x06060606u);   // 0x00 at '\n'
+        const uint32_t not_cr = __builtin_amdgcn_perm(0xffffffffu, 0xffffffffu, x[d] ^ 0x01010101u);   // 0x00 at '\r'
+        f[d] = (~not_nl & 0x02020202u) | (~not_cr & 0x01010101u);
     }
-    return I;
+    return gather_fields(f[0], f[1], f[2], f[3]);
 }
 
 // The thread's bytes: CPT chunks of 16, bytes past the end of the text read as '\n'; valid[c] = even-bit mask of the
@@ -401,17 +409,17 @@ __global__ __launch_bounds__(BLOCK) void ing_pack_kernel(const uint8_t *__restri
                 const uint64_t r = hrun++;
                 if (r < max_records) seq_start[r] = cnt + (uint32_t)__builtin_popcount(CM & (bit - 1u));
             }
-            uint32_t codes = 0, bad = 0;
+            uint32_t q[4], nzb[4];
 #pragma unroll
             for (int d = 0; d < 4; d++) {
                 // A=0x41 C=0x43 G=0x47 T=0x54: (ch >> 1) & 3 gives 0,1,3,2 -> fix the G/T order
-                uint32_t q = (x[c][d] >> 1) & 0x03030303u;
-                q ^= (q >> 1) & 0x01010101u;
-                codes |= squeeze2(q) << (8 * d);
-                const uint32_t diff = x[c][d] ^ __builtin_amdgcn_perm(0u, 0x54474341u, q);        // "ACGT"[code] == byte ?
-                const uint32_t nz = (((diff & 0x7f7f7f7fu) + 0x7f7f7f7fu) | diff) & 0x80808080u;
-                bad |= (squeeze2(nz >> 7) & 0x55u) << (8 * d);
+                q[d] = (x[c][d] >> 1) & 0x03030303u;
+                q[d] ^= (q[d] >> 1) & 0x01010101u;
+                const uint32_t diff = x[c][d] ^ __builtin_amdgcn_perm(0u, 0x54474341u, q[d]);     // "ACGT"[code] == byte ?
+                nzb[d] = ((((diff & 0x7f7f7f7fu) + 0x7f7f7f7fu) | diff) >> 7) & 0x01010101u;        // 1 in every byte outside ACGT
             }
+            uint32_t codes = gather_fields(q[0], q[1], q[2], q[3]);
+            uint32_t bad = gather_fields(nzb[0], nzb[1], nzb[2], nzb[3]);
             bad &= CM;
             uint64_t last_r = ~0ull;
             while (bad) {

@@ -346,7 +346,11 @@ def test_gpu_fasta_ingest_matches_reference_reader(amd, eng, oracle, golden_dir)
         k = int(rng.integers(1, 60))
         txt = b"".join(pieces[int(i)] * int(rng.integers(1, 4)) for i in rng.integers(0, len(pieces), size=k))
         _check_ingest(amd, eng, oracle, txt)
-    # a file that spans many 4 KiB tiles, with records of all sizes, CRLF sections and FASTQ-style quality blocks
+    # every byte value inside lines, at line starts and next to terminators (the terminator test is a byte-value trick)
+    every = b">all\n" + bytes(v for v in range(256) if v not in (10, 13)) + b"\n"
+    every += b"".join(b">v%d\n" % v + bytes([v]) + b"AC" + bytes([v]) + b"\nGT" + bytes([v, v]) + b"\n" for v in range(256))
+    _check_ingest(amd, eng, oracle, every)
+    _check_ingest(amd, eng, oracle, every.replace(b"\n", b"\r\n"))
     parts = []
     for i in range(3000):
         L = int(rng.integers(0, 700))
