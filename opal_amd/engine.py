@@ -337,19 +337,25 @@ class Engine:
 
     # ------------------------------------------------------------------ GPU-side FASTA ingest
     def ingest_fasta(self, text) -> DeviceBatch:
-        """text: bytes / numpy uint8 / path of a FASTA file.  The file's bytes go to HBM as they are; record splitting,
+        """text: bytes / numpy uint8 / path of a FASTA file / a cuda uint8 tensor.  The file's bytes go to HBM as they are; record splitting,
         newline stripping, the '+' rule and 2-bit packing happen on the device (opal_ingest_fasta)."""
         t = self.torch
-        if isinstance(text, str):
-            arr = np.fromfile(text, dtype=np.uint8)
-        elif isinstance(text, (bytes, bytearray)):
-            arr = np.frombuffer(bytes(text), dtype=np.uint8)
+        if t.is_tensor(text):                                     # the file's bytes, already in HBM
+            assert text.is_cuda and text.dtype == t.uint8 and text.is_contiguous()
+            d_text, n = text, int(text.numel())
+            if n == 0:
+                return self.upload(PackedReads.from_sequences([]))
         else:
-            arr = np.ascontiguousarray(text, dtype=np.uint8)
-        n = int(arr.size)
-        if n == 0:
-            return self.upload(PackedReads.from_sequences([]))
-        d_text = t.from_numpy(arr.copy() if not arr.flags.writeable else arr).to(self.device)
+            if isinstance(text, str):
+                arr = np.fromfile(text, dtype=np.uint8)
+            elif isinstance(text, (bytes, bytearray)):
+                arr = np.frombuffer(bytes(text), dtype=np.uint8)
+            else:
+                arr = np.ascontiguousarray(text, dtype=np.uint8)
+            n = int(arr.size)
+            if n == 0:
+                return self.upload(PackedReads.from_sequences([]))
+            d_text = t.from_numpy(arr.copy() if not arr.flags.writeable else arr).to(self.device)
         nh, nseq = C.c_uint64(), C.c_uint64()
         check(lib().opal_ingest_scan(self._h, d_text.data_ptr(), n, C.byref(nh), C.byref(nseq)), self._h)
         max_rec, T = max(int(nh.value), 1), int(nseq.value)

@@ -379,6 +379,24 @@ def default_chunk_bytes(path, world):
     return int(min(1 << 30, max(16 << 20, os.path.getsize(path) // (4 * world) + 1)))
 
 
+def _uploaded(pieces, device_index):
+    """Moves every piece to HBM on a stream of its own, inside the thread that reads the file: the copy of piece i+1
+    then runs while the predict kernel works on piece i (the copy engines are independent of the compute units)."""
+    side = None
+    for piece in pieces:
+        if piece.size == 0:
+            yield piece
+            continue
+        import torch
+        if side is None:
+            torch.cuda.set_device(device_index)
+            side = torch.cuda.Stream(device=device_index)
+        with torch.cuda.stream(side):
+            d = torch.from_numpy(piece).to(torch.device("cuda", device_index))
+        side.synchronize()                                   # the bytes are in HBM when the consumer gets the tensor
+        yield d
+
+
 class _Prefetched:
     """Runs a generator in a background thread, `depth` items ahead, starting at once: the file is being read while the
     GPU context and the model are set up, and the next piece is read while the GPU scores the current one."""
@@ -439,7 +457,7 @@ def predict(model_dir, test_dir, predict_dir, args, engine=None, chunk_bytes=Non
     # now, before the GPU context exists); records are split and 2-bit packed on the device (opal_ingest_fasta)
     if chunk_bytes is None:
         chunk_bytes = default_chunk_bytes(fasta, world)
-    pieces = _Prefetched(fasta_pieces(fasta, chunk_bytes, rank, world))
+    pieces = _Prefetched(_uploaded(fasta_pieces(fasta, chunk_bytes, rank, world), local))
     with open(pattern_file, "r") as f:
         pos = parse_patterns(f.readlines(), kmer)
     eng = engine or Engine(local)
@@ -454,7 +472,9 @@ def predict(model_dir, test_dir, predict_dir, args, engine=None, chunk_bytes=Non
     # round of pieces the class ids are concatenated on rank 0 in piece order = file order
     parts, n_frag = [], 0
     for piece in pieces:
-        if piece.size:
+        if len(piece):
+            if hasattr(piece, "record_stream"):
+                piece.record_stream(eng.torch.cuda.current_stream(eng.device))
             batch = eng.ingest_fasta(piece)
             cls, _ = eng.predict(batch, reverse)
             local_cls = cls.cpu().numpy() if batch.n else np.zeros(0, dtype=np.int32)
