@@ -56,30 +56,48 @@ def vw_class_to_taxid(inputfile, dicofile, outputfile):
         dst.writelines(by_class[str(int(float(ln.strip())))] + "\n" for ln in src)
 
 
-def _write_lines(path, table, idx, chunk=8_000_000):
-    """Writes table[idx[i]] + newline for every i at C speed: a fixed-width byte table is gathered with numpy and the
-    NUL padding is dropped from the byte stream (entries never contain NUL)."""
-    with open(path, "wb") as dst:
-        for a in range(0, idx.shape[0], chunk):
-            dst.write(table[idx[a:a + chunk]].tobytes().replace(b"\0", b""))
+class PredictionFiles:
+    """What `vw -p` followed by vw_class_to_taxid leave on disk (reference opal.py:449-451,484 and :76-88), written
+    straight from class-id arrays, a batch at a time: `pred_file` one class id per line, `taxid_file` the taxid of each
+    through vw-dico.txt.  A class the dico does not hold raises KeyError, as in the reference."""
+
+    def __init__(self, dicofile, pred_file, taxid_file):
+        with open(dicofile) as fh:
+            self.by_class = {int(cols[1]): cols[0] for cols in (ln.strip().split()[:2] for ln in fh if ln.strip())}
+        top = max(self.by_class) if self.by_class else 0
+        self.known = np.zeros(max(top, 0) + 1, dtype=bool)
+        for c in self.by_class:
+            if c >= 0:
+                self.known[c] = True
+        self.ids = np.array([("%d\n" % c).encode() for c in range(top + 1)], dtype="S")
+        self.tax = np.array([(self.by_class.get(c, "") + "\n").encode("latin-1") for c in range(top + 1)], dtype="S")
+        self.pred = open(pred_file, "wb")
+        self.taxid = open(taxid_file, "wb")
+
+    def append(self, classes, chunk=8_000_000):
+        classes = np.ascontiguousarray(classes, dtype=np.int64)
+        for a in range(0, classes.shape[0], chunk):
+            part = classes[a:a + chunk]
+            ok = (part >= 0) & (part < self.known.shape[0])
+            ok[ok] = self.known[part[ok]]
+            if not ok.all():
+                raise KeyError(str(int(part[~ok][0])))
+            # table[idx] gathered at C speed; the NUL padding of the fixed-width entries is dropped from the byte stream
+            self.pred.write(self.ids[part].tobytes().replace(b"\0", b""))
+            self.taxid.write(self.tax[part].tobytes().replace(b"\0", b""))
+
+    def close(self):
+        self.pred.close()
+        self.taxid.close()
 
 
 def write_predictions(classes, dicofile, pred_file, taxid_file):
-    """What `vw -p` followed by vw_class_to_taxid leave on disk (reference opal.py:449-451,484 and :76-88), written
-    straight from the class-id array: `pred_file` one class id per line, `taxid_file` the taxid of each through
-    vw-dico.txt.  A class the dico does not hold raises KeyError, as in the reference."""
-    classes = np.ascontiguousarray(classes, dtype=np.int64)
-    with open(dicofile) as fh:
-        by_class = {int(cols[1]): cols[0] for cols in (ln.strip().split()[:2] for ln in fh if ln.strip())}
-    top = int(classes.max()) if classes.size else 0
-    present = np.unique(classes)
-    for c in present.tolist():
-        if c not in by_class:
-            raise KeyError(str(c))
-    ids = np.array([("%d\n" % c).encode() for c in range(top + 1)], dtype="S")
-    tax = np.array([(by_class.get(c, "") + "\n").encode("latin-1") for c in range(top + 1)], dtype="S")
-    _write_lines(pred_file, ids, classes)
-    _write_lines(taxid_file, tax, classes)
+    """One-shot form of PredictionFiles."""
+    out = PredictionFiles(dicofile, pred_file, taxid_file)
+    try:
+        out.append(classes)
+    finally:
+        out.close()
 
 
 def get_fasta_and_taxid(directory):
@@ -369,14 +387,15 @@ def fasta_pieces(path, chunk_bytes, rank=0, world=1):
 
 
 def default_chunk_bytes(path, world):
-    """Piece size of predict: 1 GiB (OPAL_PREDICT_CHUNK_BYTES overrides); with several ranks at least four pieces per
+    """Piece size of predict: 256 MiB (OPAL_PREDICT_CHUNK_BYTES overrides): small enough that reading, uploading and
+    writing results overlap with scoring even for a file of a few hundred MB, large enough to fill the GPU (1.2 M reads); with several ranks at least four pieces per
     rank (but no smaller than 16 MiB) so that the ranks stay evenly loaded."""
     env = os.environ.get("OPAL_PREDICT_CHUNK_BYTES")
     if env:
         return int(env)
     if world <= 1:
-        return 1 << 30
-    return int(min(1 << 30, max(16 << 20, os.path.getsize(path) // (4 * world) + 1)))
+        return 256 << 20
+    return int(min(256 << 20, max(16 << 20, os.path.getsize(path) // (4 * world) + 1)))
 
 
 def _uploaded(pieces, device_index):
@@ -453,7 +472,7 @@ def predict(model_dir, test_dir, predict_dir, args, engine=None, chunk_bytes=Non
     prefix = os.path.join(predict_dir, "test.fragments-db")
     prediction_file = prefix + ".preds.vw"
 
-    # the file's bytes go to HBM as they are, a piece of about 1 GiB at a time (read by a background thread that starts
+    # the file's bytes go to HBM as they are, a piece of about 256 MiB at a time (read by a background thread that starts
     # now, before the GPU context exists); records are split and 2-bit packed on the device (opal_ingest_fasta)
     if chunk_bytes is None:
         chunk_bytes = default_chunk_bytes(fasta, world)
@@ -470,28 +489,35 @@ def predict(model_dir, test_dir, predict_dir, args, engine=None, chunk_bytes=Non
             f.writelines(fasta2skm.main_generator(ns, engine=eng))
     # every rank scores its own pieces (fragments are independent; no data-path collective); after each
     # round of pieces the class ids are concatenated on rank 0 in piece order = file order
-    parts, n_frag = [], 0
-    for piece in pieces:
-        if len(piece):
-            if hasattr(piece, "record_stream"):
-                piece.record_stream(eng.torch.cuda.current_stream(eng.device))
-            batch = eng.ingest_fasta(piece)
-            cls, _ = eng.predict(batch, reverse)
-            local_cls = cls.cpu().numpy() if batch.n else np.zeros(0, dtype=np.int32)
-            del batch
-        else:
-            local_cls = np.zeros(0, dtype=np.int32)
-        got = gather_in_rank_order(local_cls, dist)
-        if rank == 0:
-            parts.append(got)
-            n_frag += int(got.shape[0])
-        del piece
+    n_frag, pending = 0, None
+    out = PredictionFiles(dico, prediction_file, prefix + '.preds.taxid') if rank == 0 else None   # `vw -p` file + vw_class_to_taxid
+    try:
+        for piece in pieces:
+            cls = None
+            if len(piece):
+                if hasattr(piece, "record_stream"):
+                    piece.record_stream(eng.torch.cuda.current_stream(eng.device))
+                batch = eng.ingest_fasta(piece)
+                if batch.n:
+                    cls, _ = eng.predict(batch, reverse)          # asynchronous: the kernel runs while ...
+            if pending is not None:
+                out.append(pending)                               # ... the previous round's lines are written
+                pending = None
+            local_cls = cls.cpu().numpy() if cls is not None else np.zeros(0, dtype=np.int32)
+            got = gather_in_rank_order(local_cls, dist)
+            if rank == 0:
+                pending = got
+                n_frag += int(got.shape[0])
+            del piece
+        if pending is not None:
+            out.append(pending)
+    finally:
+        if out is not None:
+            out.close()
     if rank == 0:
-        full = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int32)
         with open(prefix + "_vwps.log", "w") as log:
             log.write("opal_amd scorer: %d fragments, oaa=%d bits=%d, kernel %s, %d rank(s)\n" % (
                 n_frag, hdr["K"], hdr["bits"], eng.predict_kernel_name(), world))
-        write_predictions(full, dico, prediction_file, prefix + '.preds.taxid')   # `vw -p` file + vw_class_to_taxid
         print("------------------------------------------------\nPredicted labels:   {}\nTotal wall clock runtime (sec): {}\n"
               "================================================".format(prefix + '.preds.taxid', (datetime.now() - starttime).total_seconds()))
         sys.stdout.flush()
