@@ -159,6 +159,15 @@ __device__ __forceinline__ uint32_t mm_fin(uint32_t h, uint32_t len)
     return h;
 }
 
+// The murmur tail of a feature name: the decimal pattern index p < 100 behind T gathered characters (T % 4 == 0, so the
+// digits start a fresh block): its term and the name's length, both wave-uniform.
+__device__ __forceinline__ uint32_t name_tail(int p, int T, uint32_t &len)
+{
+    if (p < 10) { len = (uint32_t)T + 1u; return mm_k((uint32_t)('0' + p)); }
+    len = (uint32_t)T + 2u;
+    return mm_k((uint32_t)('0' + p / 10) | ((uint32_t)('0' + p % 10) << 8));
+}
+
 // Hash of the feature name "<t gathered chars><decimal p>" (util/fasta2skm.py:140) for the window whose first
 // byte in LDS is `wb`.
 // Table-driven variant for 2-bit packed fragments (letters are only ACGT): a block of 4 gathered letters has 256
@@ -189,8 +198,9 @@ __device__ __forceinline__ uint32_t hash_name_tab(const uint8_t *wb, const uint3
                              ((uint32_t)wb[(q >> 16) & 0xffu] << 4) | ((uint32_t)wb[q >> 24] << 6);
         h = mm_hk(h, tab[idx]);
     }
-    h ^= mm_k((uint32_t)('0' + p));
-    return mm_fin(h, T + 1);
+    uint32_t len;
+    h ^= name_tail(p, T, len);
+    return mm_fin(h, len);
 }
 
 // Raw (text) fragments with t = 16: murmur over the gathered letters in registers, as hash_name_generic computes
@@ -210,9 +220,10 @@ __device__ __forceinline__ uint32_t hash_name_ascii(const uint8_t *wb, const uin
         dig = dig && (k1 & 0xf0f0f0f0u) == 0x30303030u && (((k1 & 0x0f0f0f0fu) + 0x06060606u) & 0x10101010u) == 0u;
         h = mm_h(h, k1);
     }
-    h ^= mm_k((uint32_t)('0' + p));
+    uint32_t len;
+    h ^= name_tail(p, T, len);
     all_digits = dig;
-    return mm_fin(h, T + 1);
+    return mm_fin(h, len);
 }
 
 // A pattern made of consecutive positions needs no gather: cw[i] holds the codes of bases i..i+3 packed into one
@@ -290,8 +301,8 @@ __device__ __forceinline__ void walk_fragment(const Batch &B, const Geom &G, uin
     const uint32_t len = fr.len;
     const uint8_t *src = fr.src;
     const int k = G.k, P = G.P, t = G.t;
-    const bool fast16 = (t == 16) && (P <= 10) && !raw;   // 2-bit packed: table-driven
-    const bool raw16 = (t == 16) && (P <= 10) && raw;      // text: murmur over letters in registers
+    const bool fast16 = (t == 16) && !raw;   // 2-bit packed: table-driven (P <= OPAL_MAX_P = 64: one or two index digits)
+    const bool raw16 = (t == 16) && raw;      // text: murmur over letters in registers
     const bool digit_rule = raw && !G.hash_all;
     uint32_t fill = 0;
     const uint32_t S = G.reverse ? 2u : 1u;
