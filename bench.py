@@ -250,11 +250,12 @@ def main():
         frag_per_s = world * n * args.steps / elapsed
         abytes = algorithmic_bytes_per_fragment(L, F, K, mode) * n
         achieved = abytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, prof = None, {}
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             with open(tp) as f:
-                traffic = json.load(f).get(args.workload if not (args.nfrag or args.bits or args.classes) else "", {}).get("hbm_bytes_per_launch")
+                prof = json.load(f).get(args.workload if not (args.nfrag or args.bits or args.classes) else "", {})
+                traffic = prof.get("hbm_bytes_per_launch")
         res = {
             "metric": "fragments/sec", "value": frag_per_s, "unit": "fragments/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -269,6 +270,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": abytes, "kernel_ms": kern_ms},
         }
+        for key in ("valu_issue_frac", "lds_busy_frac"):        # kernels that are ALU/LDS-bound by construction:
+            if key in prof:                                     # integer-ALU and LDS utilisation from the committed PMC passes
+                res["roofline"][key] = prof[key]
         import shutil
         res["vw_binary_on_box"] = shutil.which("vw")       # time a real vw if one exists (never seen so far)
         if world == 1 and not args.no_cpu_baseline and codes is not None:
