@@ -288,7 +288,7 @@ def test_fasta_pieces_preserve_the_reference_readers_records(tmp_path, oracle):
         path = tmp_path / ("t%d.fasta" % ti)
         path.write_bytes(text)
         want = oracle.fasta_read(text)
-        for chunk in (1, 7, 64, 1000, 5000, len(text) + 1):
+        for chunk in ((1, 7) if len(text) < 3000 else (7,)) + (64, 1000, 5000, len(text) + 1):
             got, n_pieces = [], 0
             for piece in opal.fasta_pieces(str(path), chunk):
                 got += oracle.fasta_read(piece.tobytes())
