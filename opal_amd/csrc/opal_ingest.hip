@@ -352,6 +352,24 @@ __global__ __launch_bounds__(SC_BLOCK) void ing_scan_kernel(const Sum *__restric
     }
 }
 
+// The packed stream is stored as whole dwords; only the first and the last dword of a tile can be shared with its
+// neighbours and are OR-ed in atomically, so exactly those must start as zero (zeroing the whole stream instead costs
+// a quarter of the text size in extra HBM writes).
+__global__ __launch_bounds__(BLOCK) void ing_zero_edges_kernel(const Pre *__restrict__ seg_pre, const Sum *__restrict__ tile_excl,
+                                                                uint64_t ntiles, const uint64_t *__restrict__ fin,
+                                                                uint32_t *__restrict__ out32, uint64_t cap_words)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= ntiles) return;
+    const uint64_t c0 = pre_apply(seg_pre[t / SEG_TILES], tile_excl[t]).cnt;
+    const uint64_t c1 = t + 1 < ntiles ? pre_apply(seg_pre[(t + 1) / SEG_TILES], tile_excl[t + 1]).cnt : fin[F_T];
+    const uint64_t g0 = c0 >> 4;
+    const uint64_t nd = ((c0 & 15u) + (c1 - c0) + 15u) >> 4;      // dwords the tile's pass-3 block will touch
+    if (nd == 0) return;
+    if (g0 < cap_words) out32[g0] = 0u;
+    if (g0 + nd - 1 < cap_words) out32[g0 + nd - 1] = 0u;
+}
+
 // ---- pass 3 (and 5): sequence bytes to their place ------------------------------------------------------------------
 // removes the 2-bit fields of v whose field in keep (both bits set for a kept field) is clear
 __device__ __forceinline__ uint32_t squeeze_fields(uint32_t v, uint32_t keep)
@@ -370,7 +388,7 @@ __device__ __forceinline__ uint32_t squeeze_fields(uint32_t v, uint32_t keep)
 }
 
 // RAWCOPY=false: 2-bit codes of all sequence bytes into the packed stream out32 (base p of the concatenated sequence in
-// bits 2*(p&15) of dword p>>4; the stream must be zeroed: tiles meet inside dwords), seq_start[r] for every header,
+// bits 2*(p&15) of dword p>>4; the edge dwords of every tile must be zero: tiles meet inside dwords), seq_start[r] for every header,
 // raw_flag[r] for every record that holds a byte outside ACGT.
 // RAWCOPY=true: the bytes of the records flagged raw to out8[frag_off[r] + i].
 template <bool RAWCOPY>
@@ -615,9 +633,9 @@ extern "C" int opal_ingest_fasta(opal_ctx *ctx, const uint8_t *d_text, uint64_t 
     uint32_t *raw_flag = (uint32_t *)(seq_start + (max_records + 1));
     uint32_t *out32 = reinterpret_cast<uint32_t *>(d_reads_out);
     const uint64_t cap_words = reads_cap / 4;
-    // the packed stream is assembled with atomic ORs where tiles meet: zero what it can reach (T <= nbytes bases)
-    const uint64_t zero_words = std::min<uint64_t>(cap_words, nbytes / 16 + 2);
-    OPAL_HIP_CHECK(ctx, hipMemsetAsync(out32, 0, zero_words * 4, st));
+    // the packed stream is assembled with atomic ORs where tiles meet: those dwords start as zero
+    hipLaunchKernelGGL(ing_zero_edges_kernel, dim3((unsigned)((ntiles + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, L.seg_pre, L.tile_excl, ntiles,
+                       fin, out32, cap_words);
     OPAL_HIP_CHECK(ctx, hipMemsetAsync(seq_start, 0, sizeof(uint64_t), st));   // a file without any '>' is one record that starts at 0
     OPAL_HIP_CHECK(ctx, hipMemsetAsync(raw_flag, 0, max_records * sizeof(uint32_t), st));
     hipLaunchKernelGGL(ing_pack_kernel<false>, dim3((unsigned)ntiles), dim3(BLOCK), 0, st, d_text, nbytes, L.seg_pre, L.tile_excl, fin, out32, cap_words,
