@@ -65,3 +65,41 @@ for s in range(0, n, SUB):
 print("%-34s %8.1f ms  %8.1f M fragments/s" % ("emit, all sub-batches", t_emit * 1e3, n / t_emit / 1e6))
 total += t_emit
 print("%-34s %8.1f ms  %8.1f M fragments/s  (%.2e hashes/s)" % ("whole batch", total * 1e3, n / total / 1e6, n * 548 / total))
+
+# the whole of config 5: 15 batches at coverage 1 (readme.txt:116-118 recommends -c 1 --num-batches 15; seeds 421+i as
+# opal.py:337-344), the host sampling batch i+1 in a thread while the GPU builds the views of batch i and emits it
+import queue
+import threading
+
+NB = int(sys.argv[3]) if len(sys.argv) > 3 else 15
+q = queue.Queue(maxsize=1)
+
+
+def producer():
+    for b in range(NB):
+        r = amd.Rng(421 + b)
+        q.put(r.sample_positions([GL] * G, L, 1.0))
+    q.put(None)
+
+
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+threading.Thread(target=producer, daemon=True).start()
+done = 0
+while True:
+    item = q.get()
+    if item is None:
+        break
+    pos, gi = item
+    batch = gs.fragments(pos, gi, L)
+    for s in range(0, len(pos), SUB):
+        e = min(len(pos), s + SUB)
+        sub = DeviceBatch(batch.data, batch.off[s:e], batch.len[s:e], e - s, batch.nbytes)
+        offsets = eng.feature_offsets(sub, True)
+        check(lib().opal_features(eng._h, sub.data.data_ptr(), sub.nbytes, sub.off.data_ptr(), sub.len.data_ptr(), sub.n, 1, 31,
+                                  offsets.data_ptr(), idx.data_ptr(), (e - s) * 548), eng._h)
+    done += len(pos)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print("%d batches, sampling overlapped: %d fragments in %.2f s = %.1f M fragments/s  (%.2e hashes/s)" % (
+    NB, done, dt, done / dt / 1e6, done * 548 / dt), flush=True)
