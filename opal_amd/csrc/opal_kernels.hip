@@ -33,9 +33,11 @@ __device__ __forceinline__ uint64_t feature_count(uint32_t len_word, const Geom 
 }
 
 // ------------------------------------------------------------------------------------------ emit kernels
+constexpr uint64_t EMIT_QCHUNK = 32;   // fragments per draw from the work queue: a fragment takes ~10 us here (100x less than in predict) and the
+                                       // counter is one address: 8 per draw = 83 M atomics/s held the kernel at 6.14 ms, 16-32 give 5.26, 256 5.65 (tail)
 __global__ __launch_bounds__(BLOCK) void emit_idx_kernel(Batch B, Geom G, uint32_t mask, const uint64_t *__restrict__ out_off,
                                                           uint32_t *__restrict__ out_idx, uint64_t out_cap,
-                                                          unsigned long long *__restrict__ queue)
+                                                          unsigned long long *__restrict__ queue, uint64_t qchunk)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_seq[WPB][2 * SEQB];
     __shared__ __attribute__((aligned(16))) uint32_t s_hb[WPB][HB + HB_PAD];
@@ -43,8 +45,8 @@ __global__ __launch_bounds__(BLOCK) void emit_idx_kernel(Batch B, Geom G, uint32
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = threadIdx.x / WAVE;
     fill_kmer4_table(s_tab);
-    for (uint64_t q0 = next_chunk(queue, lane); q0 < B.n; q0 = next_chunk(queue, lane))
-    for (uint64_t frag = q0; frag < min(q0 + QCHUNK, B.n); frag++) {
+    for (uint64_t q0 = next_chunk(queue, lane, qchunk); q0 < B.n; q0 = next_chunk(queue, lane, qchunk))
+    for (uint64_t frag = q0; frag < min(q0 + qchunk, B.n); frag++) {
         const uint64_t o0 = out_off[frag];
         if (o0 > out_cap || feature_count(B.len[frag], G) > out_cap - o0) continue;   // never write outside out_idx
         uint32_t *dst = out_idx + o0;
@@ -551,7 +553,9 @@ extern "C" int opal_features(opal_ctx *ctx, const uint8_t *d_reads, uint64_t rea
     rc = grid_for(ctx, (const void *)&emit_idx_kernel, n, &grid);
     if (rc) return rc;
     OPAL_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL(emit_idx_kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, B, G, mask, d_out_off, d_out_idx, out_cap, ctx->d_queue);
+    uint64_t qchunk = EMIT_QCHUNK;
+    if (const char *e = getenv("OPAL_EMIT_QCHUNK")) qchunk = std::max<uint64_t>(1, strtoull(e, nullptr, 10));   // experiments
+    hipLaunchKernelGGL(emit_idx_kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, B, G, mask, d_out_off, d_out_idx, out_cap, ctx->d_queue, qchunk);
     OPAL_HIP_CHECK(ctx, hipGetLastError());
     return OPAL_OK;
 }
