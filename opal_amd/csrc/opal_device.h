@@ -174,16 +174,28 @@ __device__ __forceinline__ uint32_t name_tail(int p, int T, uint32_t &len)
 // possible values, so its murmur term mm_k(4 letters) = two quarter-rate 32-bit multiplies + a rotate comes from a
 // 256-entry LDS table (one per block) indexed by the 4 gathered 2-bit codes (the emit kernel is VALU-bound: PMC
 // shows every SIMD issue cycle taken, profiles/r01_cfg5_emit).  wb points at staged CODES (load_* with codes=true).
-constexpr int KTAB = 256;
+constexpr int KTAB = 512;          // [0,256): mm_k(4 letters); [256,512): the hash after the FIRST block (h = 0 going in)
 __device__ __forceinline__ void fill_kmer4_table(uint32_t *tab)   // one table per block; every thread calls it once
 {
-    for (uint32_t i = threadIdx.x; i < (uint32_t)KTAB; i += BLOCK) {
+    for (uint32_t i = threadIdx.x; i < 256u; i += BLOCK) {
         uint32_t word = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) word |= ((0x54474341u >> (((i >> (2 * j)) & 3u) * 8u)) & 0xffu) << (8 * j);   // "ACGT"[code j]
-        tab[i] = mm_k(word);
+        const uint32_t km = mm_k(word);
+        tab[i] = km;
+        tab[256u + i] = mm_hk(0u, km);
     }
     __syncthreads();
+}
+// murmur finaliser for a hash whose tail term and length are already folded in
+__device__ __forceinline__ uint32_t mm_fmix(uint32_t h)
+{
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
 }
 // pq[b] = the 4 positions of block b, one per byte (the pattern row read as dwords; wave-uniform, kept in SGPRs)
 template <int T>
@@ -196,11 +208,11 @@ __device__ __forceinline__ uint32_t hash_name_tab(const uint8_t *wb, const uint3
         const uint32_t q = pq[b];
         const uint32_t idx = (uint32_t)wb[q & 0xffu] | ((uint32_t)wb[(q >> 8) & 0xffu] << 2) |
                              ((uint32_t)wb[(q >> 16) & 0xffu] << 4) | ((uint32_t)wb[q >> 24] << 6);
-        h = mm_hk(h, tab[idx]);
+        h = b == 0 ? tab[256u + idx] : mm_hk(h, tab[idx]);
     }
     uint32_t len;
-    h ^= name_tail(p, T, len);
-    return mm_fin(h, len);
+    const uint32_t tail = name_tail(p, T, len);
+    return mm_fmix(h ^ (tail ^ len));                  // tail term and length: one wave-uniform word
 }
 
 // Raw (text) fragments with t = 16: murmur over the gathered letters in registers, as hash_name_generic computes
@@ -232,11 +244,10 @@ __device__ __forceinline__ uint32_t hash_name_ascii(const uint8_t *wb, const uin
 template <int T>
 __device__ __forceinline__ uint32_t hash_name_run(const uint8_t *wbw, int p, const uint32_t *tab)
 {
-    uint32_t h = 0;
+    uint32_t h = tab[256u + wbw[0]];
 #pragma unroll
-    for (int b = 0; b < T / 4; b++) h = mm_hk(h, tab[wbw[4 * b]]);
-    h ^= mm_k((uint32_t)('0' + p));
-    return mm_fin(h, T + 1);
+    for (int b = 1; b < T / 4; b++) h = mm_hk(h, tab[wbw[4 * b]]);
+    return mm_fmix(h ^ (mm_k((uint32_t)('0' + p)) ^ (uint32_t)(T + 1)));
 }
 // cw[i] = c[i] | c[i+1]<<2 | c[i+2]<<4 | c[i+3]<<6 for the staged code bytes c[0..len) of one strand (both arrays
 // SEQB/2 bytes, 4-byte aligned); entries whose block would pass the end of the strand are don't-care.
