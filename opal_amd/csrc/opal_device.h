@@ -302,7 +302,7 @@ __device__ __forceinline__ uint32_t hash_name_generic(const uint8_t *wb, const u
 // is full and once at the end (after the optional constant feature).  flush must consume hb[0..count).
 // sq: 2*SEQB bytes of wave-private LDS (staged strands, then the packed code windows of pack_code_windows);
 // tab: the block's table of fill_kmer4_table.
-template <class Flush>
+template <int HBN = HB, class Flush>
 __device__ __forceinline__ void walk_fragment(const Batch &B, const Geom &G, uint64_t frag, uint32_t mask,
                                               bool add_const, uint32_t const_idx, uint8_t *sq, uint32_t *hb,
                                               const uint32_t *tab, int lane, Flush &&flush)
@@ -381,8 +381,8 @@ __device__ __forceinline__ void walk_fragment(const Batch &B, const Geom &G, uin
             const uint32_t U = S * W;
             uint32_t u0 = 0;
             while (u0 < U) {
-                uint32_t room = (HB - fill) / (uint32_t)P;
-                if (room < min(U - u0, (uint32_t)WAVE)) { flush(fill); fill = 0; room = HB / (uint32_t)P; }
+                uint32_t room = (HBN - fill) / (uint32_t)P;
+                if (room < min(U - u0, (uint32_t)WAVE)) { flush(fill); fill = 0; room = HBN / (uint32_t)P; }
                 const uint32_t tu = min(U - u0, room);
                 hash_windows(tu, have_cw, [&](uint32_t ul) { const uint32_t u = u0 + ul; return u < W ? u : LP + (u - W); });
                 u0 += tu;
@@ -392,8 +392,8 @@ __device__ __forceinline__ void walk_fragment(const Batch &B, const Geom &G, uin
             for (uint32_t s = 0; s < S; s++) {
                 uint32_t w0 = 0;
                 while (w0 < W) {
-                    uint32_t room = (HB - fill) / (uint32_t)P;
-                    if (room < min(W - w0, (uint32_t)WAVE)) { flush(fill); fill = 0; room = HB / (uint32_t)P; }
+                    uint32_t room = (HBN - fill) / (uint32_t)P;
+                    if (room < min(W - w0, (uint32_t)WAVE)) { flush(fill); fill = 0; room = HBN / (uint32_t)P; }
                     const uint32_t tw = min(min(W - w0, tw_seq), room);
                     load_tile(sq, src, len, raw, fr.shift, (int)s, w0, tw + (uint32_t)k - 1u, lane, fast16);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -405,7 +405,7 @@ __device__ __forceinline__ void walk_fragment(const Batch &B, const Geom &G, uin
         }
     }
     if (add_const) {
-        if (fill == HB) { flush(fill); fill = 0; }
+        if (fill == HBN) { flush(fill); fill = 0; }
         if (lane == 0) hb[fill] = const_idx;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

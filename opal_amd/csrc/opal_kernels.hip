@@ -33,6 +33,9 @@ __device__ __forceinline__ uint64_t feature_count(uint32_t len_word, const Geom 
 }
 
 // ------------------------------------------------------------------------------------------ emit kernels
+// the emit kernel only copies the hash buffer out: a smaller one than the scoring kernels' (the 548 features of a 200-bp
+// fragment still fit) halves its LDS per block and lifts the LDS limit on resident waves
+constexpr int HB_EMIT = 640;
 constexpr uint64_t EMIT_QCHUNK = 32;   // fragments per draw from the work queue: a fragment takes ~10 us here (100x less than in predict) and the
                                        // counter is one address: 8 per draw = 83 M atomics/s held the kernel at 6.14 ms, 16-32 give 5.26, 256 5.65 (tail)
 __global__ __launch_bounds__(BLOCK) void emit_idx_kernel(Batch B, Geom G, uint32_t mask, const uint64_t *__restrict__ out_off,
@@ -40,7 +43,7 @@ __global__ __launch_bounds__(BLOCK) void emit_idx_kernel(Batch B, Geom G, uint32
                                                           unsigned long long *__restrict__ queue, uint64_t qchunk)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_seq[WPB][2 * SEQB];
-    __shared__ __attribute__((aligned(16))) uint32_t s_hb[WPB][HB + HB_PAD];
+    __shared__ __attribute__((aligned(16))) uint32_t s_hb[WPB][HB_EMIT];
     __shared__ uint32_t s_tab[KTAB];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = threadIdx.x / WAVE;
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(BLOCK) void emit_idx_kernel(Batch B, Geom G, uint32
         if (o0 > out_cap || feature_count(B.len[frag], G) > out_cap - o0) continue;   // never write outside out_idx
         uint32_t *dst = out_idx + o0;
         uint32_t *hb = s_hb[wv];
-        walk_fragment(B, G, frag, mask, false, 0u, s_seq[wv], hb, s_tab, lane, [&](uint32_t cnt) {
+        walk_fragment<HB_EMIT>(B, G, frag, mask, false, 0u, s_seq[wv], hb, s_tab, lane, [&](uint32_t cnt) {
             if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {   // wave-uniform: 16-byte stores, then the tail
                 const uint32_t n4 = cnt / 4u;
                 for (uint32_t i = lane; i < n4; i += WAVE)
