@@ -103,6 +103,15 @@ int opal_rng_shuffle(opal_rng *rng, uint64_t *perm, uint64_t n);
  * F_j = max(0,len_j-k+1) * P * (reverse?2:1)  (get_all_substrings, util/fasta_functions.py:53-54).          */
 int opal_feature_offsets(opal_ctx *ctx, const uint32_t *d_frag_len, uint64_t n, int reverse, uint64_t *d_out_off);
 
+/* opal_feature_offsets for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for code under HIP
+ * graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same arguments and results; the per-tile
+ * totals of the scan live in a static 512 KiB device array of the library (one copy per GPU, held until the process
+ * ends) instead of the ctx's grown-on-demand buffer, so the call makes no hipMalloc / hipFree and does not synchronise.
+ * Limit: n <= OPAL_NOALLOC_MAX_FRAGMENTS (OPAL_ERANGE beyond).  Every call on one GPU shares that GPU's array: calls
+ * that overlap on one GPU (two ctxs / streams on the same device) race; calls on one stream are ordered and safe.   */
+#define OPAL_NOALLOC_MAX_FRAGMENTS 134217728ull
+int opal_feature_offsets_noalloc(opal_ctx *ctx, const uint32_t *d_frag_len, uint64_t n, int reverse, uint64_t *d_out_off);
+
 /* Zero-copy drawfrag.  Replaces `sample = seq[pos:pos+size]` + writing the fragment FASTA (util/drawfrag.py:38-46) for
  * genomes that are resident in HBM as a fragment batch (d_genome_off / d_genome_len = that batch's d_frag_off /
  * d_frag_len): fragment i becomes a view of frag_len bases at position d_pos[i] of genome d_genome_idx[i] (the two

@@ -37,6 +37,7 @@ PROTOTYPES = {
     "opal_sample_positions": (_int, [_vp, _vp, _u64, _u64, _f64, _vp, _vp, _u64, C.POINTER(_u64)]),
     "opal_rng_shuffle": (_int, [_vp, _vp, _u64]),
     "opal_feature_offsets": (_int, [_vp, _vp, _u64, _int, _vp]),
+    "opal_feature_offsets_noalloc": (_int, [_vp, _vp, _u64, _int, _vp]),
     "opal_fragment_views": (_int, [_vp, _vp, _vp, _u64, _vp, _vp, _u64, C.c_uint32, _vp, _vp]),
     "opal_features": (_int, [_vp, _vp, _u64, _vp, _vp, _u64, _int, _int, _vp, _vp, _u64]),
     "opal_feature_names": (_int, [_vp, _vp, _u64, _vp, _vp, _u64, _int, _vp, _vp, _u64]),

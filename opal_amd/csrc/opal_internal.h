@@ -28,6 +28,7 @@ struct opal_ctx {
     // scratch for the offsets scan
     unsigned long long *d_queue = nullptr;   // work-queue counter of the predict kernel (allocated with the ctx)
     uint64_t *d_block_sums = nullptr;
+    unsigned long long *d_static_sums = nullptr;   // this device's copy of the static scratch (hipGetSymbolAddress; never freed)
     uint64_t block_sums_cap = 0;
     // scratch of the FASTA ingest (grown on demand)
     void *ing_tiles = nullptr, *ing_rec = nullptr;

@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -267,6 +268,36 @@ __global__ __launch_bounds__(BLOCK) void scan_sums_kernel(uint64_t *__restrict__
     if (threadIdx.x == 0) out_off[n] = s_carry;
 }
 
+// Scratch of opal_feature_offsets_noalloc: the per-tile totals of the offsets scan live in a file-scope device array
+// instead of a hipMalloc'ed buffer, for callers that must not allocate (HIP graph capture, serving loops).  Every GPU
+// the library runs on holds its own copy (512 KiB) until the process ends.  In host code the NAME `scratch` is only a
+// stand-in for the symbol: the device address comes from hipGetSymbolAddress, once per device (static_scratch_for),
+// and only that pointer is ever handed to kernels.
+constexpr uint64_t NOALLOC_MAX_TILES = 65536;                                  // x 8 B = 512 KiB
+constexpr uint64_t NOALLOC_MAX_FRAGMENTS = NOALLOC_MAX_TILES * SCAN_TILE;      // 134 217 728 fragments per call
+}  // namespace
+static __device__ __align__(256) unsigned long long scratch[NOALLOC_MAX_TILES];   // file scope
+namespace {
+
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mu;
+unsigned long long *g_scratch_ptr[MAX_DEVICES] = {};   // per device: that GPU's copy of `scratch`
+
+// the device must be current; called from opal_ctx_create (the library's set-up call), once per device
+int static_scratch_for(int device, unsigned long long **out, std::string *err)
+{
+    if (device < 0 || device >= MAX_DEVICES) { *err = "device id beyond the static scratch table"; return OPAL_EINVAL; }
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        unsigned long long *p = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) { *err = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e); return OPAL_EHIP; }
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return OPAL_OK;
+}
+
 // ------------------------------------------------------------------------------------------ table padding
 __global__ void mirror_head_kernel(float *w, uint64_t n_slots, uint32_t pad)
 {
@@ -377,6 +408,15 @@ extern "C" int opal_ctx_create(int device_id, void *stream, opal_ctx **out)
         std::string m = std::string("opal_ctx_create: ") + hipGetErrorString(e);
         delete ctx;
         return opal::fail(nullptr, OPAL_EHIP, m);
+    }
+    {   // this device's copy of the static scratch (opal_feature_offsets_noalloc); device_id is current here
+        std::string m;
+        const int rc = static_scratch_for(device_id, &ctx->d_static_sums, &m);
+        if (rc) {
+            (void)hipFree(ctx->d_queue);
+            delete ctx;
+            return opal::fail(nullptr, rc, "opal_ctx_create: " + m);
+        }
     }
     *out = ctx;
     return OPAL_OK;
@@ -516,6 +556,36 @@ extern "C" int opal_feature_offsets(opal_ctx *ctx, const uint32_t *d_frag_len, u
     if (ntiles) {
         hipLaunchKernelGGL(scan_tiles_kernel<true>, dim3((unsigned)ntiles), dim3(BLOCK), 0, ctx->stream, d_frag_len, n, ctx->k,
                            ctx->P, strands, ctx->d_block_sums, d_out_off);
+        OPAL_HIP_CHECK(ctx, hipGetLastError());
+    }
+    return OPAL_OK;
+}
+
+// Same three launches as opal_feature_offsets, with the tile totals in this GPU's static scratch: no hipMalloc, no
+// hipFree, no synchronisation.  Pass 1 overwrites every total it later reads, so nothing has to start at zero.
+extern "C" int opal_feature_offsets_noalloc(opal_ctx *ctx, const uint32_t *d_frag_len, uint64_t n, int reverse, uint64_t *d_out_off)
+{
+    if (!ctx) return opal::fail(nullptr, OPAL_EINVAL, "opal_feature_offsets_noalloc: null ctx");
+    if (ctx->P == 0) return opal::fail(ctx, OPAL_ESTATE, "opal_feature_offsets_noalloc: opal_set_patterns has not been called");
+    if (!d_out_off || (n && !d_frag_len)) return opal::fail(ctx, OPAL_EINVAL, "opal_feature_offsets_noalloc: null pointer");
+    if (n > NOALLOC_MAX_FRAGMENTS)
+        return opal::fail(ctx, OPAL_ERANGE, "opal_feature_offsets_noalloc: n exceeds the static scratch (at most 134217728 fragments per call); "
+                                            "split the batch or use opal_feature_offsets");
+    if (!ctx->d_static_sums) return opal::fail(ctx, OPAL_ESTATE, "opal_feature_offsets_noalloc: static scratch not resolved");
+    OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    unsigned long long *sums = ctx->d_static_sums;     // the device address, never the symbol's name
+    const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    const int strands = reverse ? 2 : 1;
+    if (ntiles) {
+        hipLaunchKernelGGL(scan_tiles_kernel<false>, dim3((unsigned)ntiles), dim3(BLOCK), 0, ctx->stream, d_frag_len, n, ctx->k,
+                           ctx->P, strands, (uint64_t *)sums, d_out_off);
+        OPAL_HIP_CHECK(ctx, hipGetLastError());
+    }
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(BLOCK), 0, ctx->stream, (uint64_t *)sums, ntiles, n, d_out_off);
+    OPAL_HIP_CHECK(ctx, hipGetLastError());
+    if (ntiles) {
+        hipLaunchKernelGGL(scan_tiles_kernel<true>, dim3((unsigned)ntiles), dim3(BLOCK), 0, ctx->stream, d_frag_len, n, ctx->k,
+                           ctx->P, strands, (uint64_t *)sums, d_out_off);
         OPAL_HIP_CHECK(ctx, hipGetLastError());
     }
     return OPAL_OK;
