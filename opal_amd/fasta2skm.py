@@ -24,26 +24,25 @@ create_pattern_getters = parse_patterns
 
 
 def update_dictionary(labels, dico_file):
-    """Updates the dictionary file converting labels to vwid with an iterator over new labels."""
-    label2vwid = {}
-    vwidset = set()
+    """Extends the label -> class id table kept in `dico_file` with the labels of `labels` (an iterable of lines) and
+    returns it.  Behaviour of util/fasta2skm.py:19-44 as the golden cases record it: rows of an existing file are
+    `<label> <id>` (first two words; a later row wins), a label not seen before gets the largest id so far plus one
+    (1 in an empty table), the file is rewritten as `<label>\t<id>` rows in first-seen order."""
+    table, top = {}, None
     if os.path.isfile(dico_file):
-        with open(dico_file, "r") as df:
-            for line in df.readlines():
-                label, vwid_str = line.strip().split()[:2]
-                vwid = int(vwid_str)
-                label2vwid[label] = vwid
-                vwidset.add(vwid)
-    for line in labels:
-        label = line.rstrip("\n")
-        if label not in label2vwid:
-            vwid = 1 if len(vwidset) == 0 else max(vwidset) + 1
-            label2vwid[label] = vwid
-            vwidset.add(vwid)
-    with open(dico_file, "w") as df:
-        for label, vwid in list(label2vwid.items()):
-            df.write("{}\t{}\n".format(label, vwid))
-    return label2vwid
+        with open(dico_file, "r") as fh:
+            for row in fh:
+                name, num = row.strip().split()[:2]          # ValueError on a row with fewer than two words
+                table[name] = int(num)
+                top = table[name] if top is None else max(top, table[name])
+    for row in labels:
+        name = row.rstrip("\n")
+        if name not in table:
+            top = 1 if top is None else top + 1
+            table[name] = top
+    with open(dico_file, "w") as fh:
+        fh.writelines("%s\t%d\n" % item for item in table.items())
+    return table
 
 
 def vw_text_lines(engine: Engine, seqs, reverse, labels=None, chunk=4096):

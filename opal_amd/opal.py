@@ -50,8 +50,11 @@ def extract_column_two(infile, outfile):
 def vw_class_to_taxid(inputfile, dicofile, outputfile):
     """Class ids (one per line, '3' or '3.000000') -> taxids through vw-dico.txt (reference opal.py:76-88).
     An id that the dico does not hold raises KeyError, as in the reference."""
+    by_class = {}
     with open(dicofile) as fh:
-        by_class = {cols[1]: cols[0] for cols in (ln.strip().split()[:2] for ln in fh)}
+        for ln in fh:
+            taxid, klass = ln.strip().split()[:2]            # ValueError on a row with fewer than two words, as there
+            by_class[klass] = taxid
     with open(inputfile) as src, open(outputfile, "w") as dst:
         dst.writelines(by_class[str(int(float(ln.strip())))] + "\n" for ln in src)
 
@@ -62,8 +65,17 @@ class PredictionFiles:
     through vw-dico.txt.  A class the dico does not hold raises KeyError, as in the reference."""
 
     def __init__(self, dicofile, pred_file, taxid_file):
+        # the reference looks classes up as str(int(float(line))) (opal.py:87): only rows whose id column is an integer
+        # in that canonical spelling can ever match, the others are dead rows
+        self.by_class = {}
         with open(dicofile) as fh:
-            self.by_class = {int(cols[1]): cols[0] for cols in (ln.strip().split()[:2] for ln in fh if ln.strip())}
+            for ln in fh:
+                taxid, klass = ln.strip().split()[:2]
+                try:
+                    if str(int(klass)) == klass:
+                        self.by_class[int(klass)] = taxid
+                except ValueError:
+                    pass
         top = max(self.by_class) if self.by_class else 0
         self.known = np.zeros(max(top, 0) + 1, dtype=bool)
         for c in self.by_class:
@@ -126,8 +138,10 @@ def evaluate_predictions(reffile, predfile):
         pred = fin.read().splitlines()
     with open(reffile, "r") as fin:
         ref = fin.read().splitlines()
+    if len(pred) != len(ref):          # the reference builds a pandas frame from both columns (opal.py:123), which refuses
+        raise ValueError("All arrays must be of the same length")
     correct = np.array([x == y for x, y in zip(pred, ref)], dtype=bool)
-    refs = np.array(ref[:len(correct)])
+    refs = np.array(ref)
     classes, inv = np.unique(refs, return_inverse=True)
     species = np.bincount(inv, weights=correct, minlength=len(classes)) / np.maximum(np.bincount(inv, minlength=len(classes)), 1)
     micro, macro, median = float(np.mean(correct)), float(np.mean(species)), float(np.median(species))
@@ -145,7 +159,9 @@ def evaluate_predictions_gpu(reffile, predfile, engine):
         pred = fin.read().splitlines()
     with open(reffile, "r") as fin:
         ref = fin.read().splitlines()
-    n = min(len(pred), len(ref))
+    if len(pred) != len(ref):
+        raise ValueError("All arrays must be of the same length")
+    n = len(ref)
     ids = {}
     r = np.fromiter((ids.setdefault(x, len(ids)) for x in ref[:n]), dtype=np.int32, count=n)
     nref = len(ids)
@@ -196,6 +212,34 @@ def frag(test_dir, frag_dir, args):
           "================================================".format((datetime.now() - starttime).total_seconds()))
     sys.stdout.flush()
     return 0
+
+
+# ------------------------------------------------------------------ the training stream (reference opal.py:329-367)
+def batch_label(taxid_line):
+    """The label a genome's fragments carry in a training batch: drawfrag writes `<first word of the record name>\t<taxid
+    line>` per fragment (util/drawfrag.py:29,47) and extract_column_two keeps the second word of that row (opal.py:65-74),
+    i.e. the first word of the taxid line, or '' when the line is blank or missing."""
+    words = taxid_line.split()
+    return words[0] if words else ""
+
+
+def draw_training_batch(rng, seed, genome_len, genome_taxid, frag_length, coverage, dico):
+    """One batch of the example stream, in the order the reference pipes it to vw (opal.py:329-367): drawfrag.main with
+    `-s seed` (random.seed, then one randint per fragment, genome by genome) -> extract_column_two -> the dico update of
+    fasta2skm.main_generator (ids in first-seen order of the batch's labels) -> random.shuffle continuing the same stream.
+    genome_taxid[g] = line g of the .taxid file ('' when the file is shorter than the fasta).  Returns, per example of the
+    shuffled stream, (class id int32, position uint64, genome index uint32); `dico` is updated on disk like the
+    reference's vw-dico.txt.  Pinned by tests/golden/train_stream.json (the reference's own functions run in this order)."""
+    rng.seed(seed)
+    fpos, fgen = rng.sample_positions(genome_len, frag_length, coverage)
+    labels = [batch_label(t) for t in genome_taxid]
+    sampled = np.unique(fgen).tolist()                       # fragments come genome by genome: first-seen order = genome order
+    label2vwid = fasta2skm.update_dictionary((labels[g] + "\n" for g in sampled), dico)
+    genome_vwid = np.zeros(len(genome_len), dtype=np.int32)
+    for g in sampled:
+        genome_vwid[g] = label2vwid[labels[g]]
+    perm = rng.shuffle_perm(len(fpos)).astype(np.int64)      # shuffled[i] = original[perm[i]]
+    return np.ascontiguousarray(genome_vwid[fgen.astype(np.int64)][perm]), fpos[perm], fgen[perm]
 
 
 # ------------------------------------------------------------------ train (reference opal.py:208-389)
@@ -264,26 +308,12 @@ def train(ref_dir, model_dir, args, engine=None):
     for i in range(num_batches):
         seed = seed + 1                                      # 421, 422, ... (reference opal.py:329)
         print("Drawing fragments for batch {}".format(i))
-        rng.seed(seed)                                       # drawfrag.main(... "-s", seed) -> random.seed (drawfrag.py:23-24)
-        fpos, fgen = rng.sample_positions(genome_len, frag_length, coverage)
+        vwid, fpos, fgen = draw_training_batch(rng, seed, genome_len, genome_taxid, frag_length, coverage, dico)
         n_frag = len(fpos)
-        # the dico assigns ids in first-seen order of the batch's taxid column (fasta2skm.py:30-40): fragments come
-        # genome by genome, so that is the order of the genomes that produced at least one fragment
-        first_seen = [genome_taxid[g] for g in sorted(set(fgen.tolist()))]
-        taxid_batch = os.path.join(model_dir, "train.batch-{}.taxid".format(i))
-        with open(taxid_batch, "w") as f:                     # the transient file the reference writes and deletes
-            f.write("".join("%s\n" % t for t in first_seen))
-        with open(taxid_batch, "r") as f:
-            label2vwid = fasta2skm.update_dictionary(f, dico)
-        os.remove(taxid_batch)
-        genome_vwid = np.array([label2vwid.get(t, 0) for t in genome_taxid], dtype=np.int32)
-        vwid = genome_vwid[fgen.astype(np.int64)]
         if vwid.size and vwid.max() > num_labels:
             raise ValueError("class id %d exceeds --oaa %d" % (vwid.max(), num_labels))
         print("Getting training set ...")
         print("Shuffling training set ...")
-        perm = rng.shuffle_perm(n_frag).astype(np.int64)      # random.shuffle on the same stream (reference opal.py:363)
-        vwid, fpos, fgen = np.ascontiguousarray(vwid[perm]), fpos[perm], fgen[perm]
         held = (np.arange(seen + 1, seen + n_frag + 1) % HOLDOUT_PERIOD == 0) if multipass else np.zeros(n_frag, dtype=bool)
         seen += n_frag
         keep = ~held

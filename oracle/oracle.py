@@ -336,7 +336,10 @@ def vw_class_to_taxid(pred_lines, dico_text):
 
 
 def evaluate(ref, pred):
-    """micro / macro / median per-reference-class accuracy (opal.py:111-131)."""
+    """micro / macro / median per-reference-class accuracy (opal.py:111-131); files of unequal length make the
+    reference's pandas frame raise ValueError (opal.py:123).  Pinned by tests/golden/opal_helpers.json."""
+    if len(ref) != len(pred):
+        raise ValueError("All arrays must be of the same length")
     correct = [x == y for x, y in zip(pred, ref)]
     by = {}
     for r, c in zip(ref, correct):

@@ -12,6 +12,12 @@ The reference modules exercised (file:line in /root/reference):
   util/fasta_functions.py:9-54    fasta_reader, reverse_complement, get_all_substrings
   util/fasta2skm.py:19-44,47-84,120-141  update_dictionary, main_generator, gen_features -> skm_*.json
   CPython `random` (what drawfrag.py:24,38 and opal.py:363 call)          -> pyrandom.json
+  opal.py:52-88,111-138           unique_lines, extract_column_two, vw_class_to_taxid, evaluate_predictions
+                                                                          -> opal_helpers.json
+  opal.py:329-367                 one training batch as train() assembles it: drawfrag.main (seed 421+i) ->
+                                  extract_column_two -> fasta2skm.main_generator(taxid, dico) -> random.shuffle
+                                  (the reference's own functions called in train()'s order; train() itself cannot run:
+                                  it starts `vw`)                         -> train_stream.json
 The murmur indices use sklearn.utils.murmurhash3_32 (an independent MurmurHash3_x86_32) because the
 reference's hashing lives in the external `vw` binary, which is absent: the VW side
 of parity is UNPINNED.
@@ -28,8 +34,14 @@ sys.dont_write_bytecode = True
 REF = "/root/reference/util"
 sys.path.insert(0, REF)
 
+import warnings  # noqa: E402
+
 import numpy as np  # noqa: E402
+warnings.simplefilter("ignore", FutureWarning)        # pandas' note on .agg(np.mean) inside the reference
 from sklearn.utils import murmurhash3_32  # noqa: E402
+
+sys.path.insert(1, "/root/reference")
+import opal as ref_opal  # noqa: E402  (the reference's opal.py; argparse/pandas/sklearn are present)
 
 import drawfrag  # noqa: E402
 import fasta2skm  # noqa: E402
@@ -254,7 +266,128 @@ def gen_primitives():
         json.dump({"reverse_complement": rc, "fasta_reader": readers, "get_all_substrings": subs}, f)
 
 
+# ---------------------------------------------------------------- opal.py host helpers (opal.py:52-88,111-138)
+def _captured(fn, *a):
+    so = sys.stdout
+    sys.stdout = io.StringIO()
+    try:
+        fn(*a)
+        return sys.stdout.getvalue()
+    finally:
+        sys.stdout = so
+
+
+def gen_opal_helpers():
+    out = {"unique_lines": [], "extract_column_two": [], "vw_class_to_taxid": [], "evaluate_predictions": []}
+    with tempfile.TemporaryDirectory() as d:
+        a, b, c = os.path.join(d, "a"), os.path.join(d, "b"), os.path.join(d, "c")
+        for txt in ["562\n1280\n562\n", "562\n1280\n562", "", "\n\n", "a\nA\n a\na \n", "x\r\nx\n"]:
+            open(a, "w", newline="").write(txt)
+            out["unique_lines"].append([txt, ref_opal.unique_lines(a)])
+        for txt in ["gi|1|\t562\ngi|2|\t1280\n", "one\n\nthree words here\n a  b\tc\n", "x\ty", "", "n\t12 34\n"]:
+            open(a, "w").write(txt)
+            ref_opal.extract_column_two(a, b)
+            out["extract_column_two"].append([txt, open(b).read()])
+        dico = "562\t1\n1280\t2\nNC_000913.3\t3\nlabel with\t4\n9\t7\n"
+        open(b, "w").write(dico)
+        for txt in ["3\n1\n1\n2\n", "3.000000\n1.0\n7\n", " 2 \n", ""]:
+            open(a, "w").write(txt)
+            ref_opal.vw_class_to_taxid(a, b, c)
+            out["vw_class_to_taxid"].append({"preds": txt, "dico": dico, "taxids": open(c).read(), "error": None})
+        for txt, err in [("5\n", "KeyError"), ("1\nx\n", "ValueError")]:
+            open(a, "w").write(txt)
+            try:
+                ref_opal.vw_class_to_taxid(a, b, c)
+                raise SystemExit("expected " + err)
+            except (KeyError, ValueError) as e:
+                assert type(e).__name__ == err
+            out["vw_class_to_taxid"].append({"preds": txt, "dico": dico, "taxids": None, "error": err})
+        rng = random.Random(8)
+        ref_big = [str(rng.choice([562, 1280, 1313, 4932, 9, 77])) for _ in range(500)]
+        pred_big = [x if rng.random() < 0.8 else str(rng.choice([562, 1280, 5])) for x in ref_big]
+        cases = [
+            (["1", "2", "2", "3"], ["1", "2", "1", "3"]),
+            (["a", "a", "b", "b", "b", "c"], ["a", "b", "b", "b", "a", "x"]),             # class of pred absent from ref, and vice versa
+            (["1", "1", "2", "2", "2"], ["1", "1", "2"]),                                  # pred shorter than ref
+            (["1", "2"], ["1", "2", "2", "2"]),                                            # pred longer than ref
+            (["7"], ["7"]),
+            (["1", "2", "3", "4"], ["4", "3", "2", "1"]),
+            (ref_big, pred_big),
+        ]
+        for ref, pred in cases:
+            open(a, "w").write("".join(x + "\n" for x in ref))
+            open(b, "w").write("".join(x + "\n" for x in pred))
+            try:                                   # files of unequal length: pandas refuses the frame (opal.py:123) -> ValueError
+                rec = {"ref": ref, "pred": pred, "stdout": _captured(ref_opal.evaluate_predictions, a, b), "error": None}
+            except ValueError:
+                assert len(ref) != len(pred)
+                rec = {"ref": ref, "pred": pred, "stdout": None, "error": "ValueError"}
+            out["evaluate_predictions"].append(rec)
+    with open(os.path.join(HERE, "opal_helpers.json"), "w") as f:
+        json.dump(out, f)
+
+
+# ---------------------------------------------------------------- the training stream (opal.py:329-367)
+def gen_train_stream():
+    import hashlib
+    rng = random.Random(77)
+    lens = (900, 150, 2300, 99, 1200, 640, 100)
+    genomes = [rand_dna(rng, n, "ACGT" if i != 4 else "ACGTacgtN") for i, n in enumerate(lens)]
+    fasta = ""
+    for i, g in enumerate(genomes):
+        fasta += ">gi|%d|ref|NC_%04d| genome %d\n" % (i + 1, i, i)
+        fasta += "\n".join(g[j:j + 80] for j in range(0, len(g), 80)) + "\n"
+    # two genomes share a taxid, one taxid has a second column (extract_column_two keeps its first word only)
+    taxid_full = "562\n1280\n562\n77\n1313 strainB\n4932\n1280\n"
+    # the last genome has NO taxid line: its label is '' (a second batch would die re-reading the dico line "\t<id>",
+    # fasta2skm.py:26, so this case has one batch)
+    taxid_short = "562\n1280\n562\n77\n1313 strainB\n4932\n"
+    pat = os.path.join(HERE, "patterns_k64_t16_m1_s7.txt")
+    cases = []
+    for (L, cov, nb, reverse, taxid_text) in [(100, 1.0, 2, True, taxid_full), (64, 2.5, 3, False, taxid_full),
+                                              (100, 0.7, 1, True, taxid_short)]:
+        with tempfile.TemporaryDirectory() as d:
+            fa, tx, dico = os.path.join(d, "train.fasta"), os.path.join(d, "train.taxid"), os.path.join(d, "vw-dico.txt")
+            open(fa, "w").write(fasta)
+            open(tx, "w").write(taxid_text)
+            seed, batches = 420, []
+            for i in range(nb):                                   # opal.py:328-367, with the reference's own functions
+                seed = seed + 1
+                prefix = os.path.join(d, "train.batch-%d" % i)
+                _captured(drawfrag.main, ["-i", fa, "-t", tx, "-l", str(L), "-c", str(cov), "-o", prefix + ".fasta",
+                                          "-g", prefix + ".gi2taxid", "-s", str(seed)])
+                import gc
+                gc.collect()                                      # drawfrag never closes its files
+                ref_opal.extract_column_two(prefix + ".gi2taxid", prefix + ".taxid")
+                ns = argparse.Namespace(input=prefix + ".fasta", taxid=prefix + ".taxid", kmer=64, dico=dico, output=None,
+                                        pattern=pat, reverse=reverse)
+                training_list = [line.rstrip("\n") for line in fasta2skm.main_generator(ns)]
+                frags = [s for _, s in fasta_functions.fasta_reader(open(prefix + ".fasta"))]
+                assert len(frags) == len(training_list)
+                state = random.getstate()
+                random.shuffle(training_list)                     # opal.py:363: the stream drawfrag seeded goes on
+                after = random.getstate()
+                random.setstate(state)
+                order = list(range(len(frags)))
+                random.shuffle(order)                             # same length -> same permutation
+                assert random.getstate() == after
+                labels = [ln.split(" ", 1)[0] for ln in training_list]
+                text = "".join("%s\n" % item for item in training_list).encode()      # what opal.py:366-367 pipes to vw
+                batches.append({"seed": seed, "labels": labels, "fragments": [frags[j] for j in order],
+                                "dico_after": open(dico).read(), "vw_text_sha256": hashlib.sha256(text).hexdigest(),
+                                "vw_text_bytes": len(text)})
+            cases.append({"fasta": fasta, "taxid": taxid_text, "frag_length": L, "coverage": cov, "reverse": reverse,
+                          "pattern": os.path.basename(pat), "kmer": 64, "num_labels": ref_opal.unique_lines(tx),
+                          "batches": batches})
+    with open(os.path.join(HERE, "train_stream.json"), "w") as f:
+        json.dump(cases, f)
+
+
 if __name__ == "__main__":
+    gen_opal_helpers()
+    gen_train_stream()
+    if "--only-new" in sys.argv:
+        sys.exit(0)
     gen_patterns()
     gen_drawfrag()
     gen_pyrandom()

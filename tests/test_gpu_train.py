@@ -196,6 +196,60 @@ def test_cli_train_multipass_holdout_and_early_stop(amd, tmp_path):
     eng.close()
 
 
+def test_gpu_eval_counts_match_reference_output(amd, golden_dir, tmp_path, capsys):
+    """opal_eval_counts (through evaluate_predictions_gpu) prints what the reference's evaluate_predictions printed
+    (tests/golden/opal_helpers.json, reference opal.py:111-138), and refuses files of unequal length like it."""
+    import json
+    from opal_amd import opal
+    with open(os.path.join(golden_dir, "opal_helpers.json")) as f:
+        cases = json.load(f)["evaluate_predictions"]
+    eng = amd.Engine(0)
+    rf, pf = tmp_path / "ref.taxid", tmp_path / "pred.taxid"
+    capsys.readouterr()
+    for case in cases:
+        rf.write_text("".join(x + "\n" for x in case["ref"]))
+        pf.write_text("".join(x + "\n" for x in case["pred"]))
+        if case["error"]:
+            with pytest.raises(ValueError):
+                opal.evaluate_predictions_gpu(str(rf), str(pf), eng)
+            continue
+        opal.evaluate_predictions_gpu(str(rf), str(pf), eng)
+        assert capsys.readouterr().out == case["stdout"]
+    eng.close()
+
+
+def test_training_stream_vw_text_matches_reference(amd, golden_dir):
+    """End to end pin of the train data path: the examples of draw_training_batch, turned into VW text lines with the
+    GPU-gathered feature names, are byte for byte what the reference pipes to vw for seeds 421, 422, ... (sha256 of the
+    shuffled training_list, tests/golden/train_stream.json; reference opal.py:329-367)."""
+    import hashlib
+    import io
+    import json
+    import tempfile
+    from opal_amd import fasta2skm, opal
+    from opal_amd.fasta_functions import fasta_reader
+    with open(os.path.join(golden_dir, "train_stream.json")) as f:
+        cases = json.load(f)
+    eng = amd.Engine(0)
+    for case in cases:
+        with open(os.path.join(golden_dir, case["pattern"])) as f:
+            eng.set_patterns(amd.parse_patterns(f.readlines(), case["kmer"]), case["kmer"])
+        genomes = [s for _, s in fasta_reader(io.StringIO(case["fasta"]))]
+        taxid_lines = case["taxid"].splitlines()
+        genome_taxid = [taxid_lines[g] if g < len(taxid_lines) else "" for g in range(len(genomes))]
+        L = case["frag_length"]
+        rng = amd.Rng()
+        with tempfile.TemporaryDirectory() as d:
+            for b in case["batches"]:
+                vwid, pos, gen = opal.draw_training_batch(rng, b["seed"], [len(x) for x in genomes], genome_taxid, L,
+                                                          case["coverage"], os.path.join(d, "vw-dico.txt"))
+                frags = [genomes[g][p:p + L].encode("latin-1") for p, g in zip(pos.tolist(), gen.tolist())]
+                text = b"".join(fasta2skm.vw_text_lines(eng, frags, case["reverse"], vwid.tolist()))
+                assert len(text) == b["vw_text_bytes"]
+                assert hashlib.sha256(text).hexdigest() == b["vw_text_sha256"]
+    eng.close()
+
+
 def test_gpu_eval_counts_match_host(amd, oracle, tmp_path, capsys):
     from opal_amd import opal
     rng = np.random.default_rng(1)

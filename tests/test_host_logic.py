@@ -248,6 +248,72 @@ def test_cli_parser_matches_reference_defaults():
         opal.get_fasta_and_taxid(tempfile.mkdtemp())
 
 
+def test_opal_helpers_match_reference(golden_dir, tmp_path, capsys):
+    """unique_lines, extract_column_two, vw_class_to_taxid (+ the array writer) and evaluate_predictions against what the
+    reference's own functions returned / wrote / printed (tests/golden/opal_helpers.json, reference opal.py:52-88,111-138)."""
+    from opal_amd import opal
+    g = _load(golden_dir, "opal_helpers.json")
+    a, b, c = str(tmp_path / "a"), str(tmp_path / "b"), str(tmp_path / "c")
+    for txt, want in g["unique_lines"]:
+        open(a, "w", newline="").write(txt)
+        assert opal.unique_lines(a) == want, txt
+    for txt, want in g["extract_column_two"]:
+        open(a, "w").write(txt)
+        opal.extract_column_two(a, b)
+        assert open(b).read() == want, txt
+    for case in g["vw_class_to_taxid"]:
+        open(a, "w").write(case["preds"])
+        open(b, "w").write(case["dico"])
+        if case["error"]:
+            with pytest.raises({"KeyError": KeyError, "ValueError": ValueError}[case["error"]]):
+                opal.vw_class_to_taxid(a, b, c)
+            if case["error"] == "KeyError":                  # the array writer of predict refuses the same class
+                with pytest.raises(KeyError):
+                    opal.write_predictions(np.array([int(float(x)) for x in case["preds"].split()]), b, a + ".vw", c)
+            continue
+        opal.vw_class_to_taxid(a, b, c)
+        assert open(c).read() == case["taxids"]
+        cls = np.array([int(float(x)) for x in case["preds"].split()], dtype=np.int32)
+        opal.write_predictions(cls, b, a + ".vw", c + ".2")
+        assert open(c + ".2").read() == case["taxids"]
+        assert open(a + ".vw").read() == "".join("%d\n" % x for x in cls)
+    capsys.readouterr()
+    for case in g["evaluate_predictions"]:
+        open(a, "w").write("".join(x + "\n" for x in case["ref"]))
+        open(b, "w").write("".join(x + "\n" for x in case["pred"]))
+        if case["error"]:
+            with pytest.raises(ValueError):
+                opal.evaluate_predictions(a, b)
+            continue
+        opal.evaluate_predictions(a, b)
+        assert capsys.readouterr().out == case["stdout"]
+
+
+def test_training_stream_matches_reference(golden_dir, tmp_path):
+    """The example stream train() feeds the learner (class id, genome, position per example, in order) and the dico it
+    leaves, against the reference's drawfrag.main -> extract_column_two -> main_generator(taxid, dico) -> random.shuffle
+    run in train()'s order for seeds 421, 422, ... (tests/golden/train_stream.json, reference opal.py:329-367)."""
+    import opal_amd
+    from opal_amd import opal
+    from opal_amd.fasta_functions import fasta_reader
+    for ci, case in enumerate(_load(golden_dir, "train_stream.json")):
+        genomes = [s for _, s in fasta_reader(io.StringIO(case["fasta"]))]
+        taxid_lines = case["taxid"].splitlines()
+        genome_taxid = [taxid_lines[g] if g < len(taxid_lines) else "" for g in range(len(genomes))]
+        tx = tmp_path / ("t%d.taxid" % ci)
+        tx.write_text(case["taxid"])
+        assert opal.unique_lines(str(tx)) == case["num_labels"]
+        dico = str(tmp_path / ("dico%d.txt" % ci))
+        rng = opal_amd.Rng()
+        L = case["frag_length"]
+        for b in case["batches"]:
+            vwid, pos, gen = opal.draw_training_batch(rng, b["seed"], [len(x) for x in genomes], genome_taxid, L,
+                                                      case["coverage"], dico)
+            assert [str(v) for v in vwid.tolist()] == b["labels"]
+            assert [genomes[g][p:p + L] for p, g in zip(pos.tolist(), gen.tolist())] == b["fragments"]
+            assert open(dico).read() == b["dico_after"]
+
+
 def test_write_predictions_equals_reference_style_files(tmp_path):
     """write_predictions (array -> `vw -p` file + taxid file) leaves the same bytes as the reference's two steps
     (opal.py:449-451 then vw_class_to_taxid, opal.py:76-88), including the KeyError for a class outside the dico."""

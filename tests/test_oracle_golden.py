@@ -6,6 +6,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 
 
 def _load(golden_dir, name):
@@ -132,6 +133,17 @@ def test_dico_evolution(oracle, golden_dir):
 
 
 # ---------------------------------------------------------------- scoring: self-consistency only (VW unpinned)
+def test_evaluate_matches_reference_output(oracle, golden_dir):
+    """oracle.evaluate against the three numbers the reference's evaluate_predictions printed (opal.py:111-131)."""
+    for case in _load(golden_dir, "opal_helpers.json")["evaluate_predictions"]:
+        if case["error"]:
+            with pytest.raises(ValueError):
+                oracle.evaluate(case["ref"], case["pred"])
+            continue
+        micro, macro, median = oracle.evaluate(case["ref"], case["pred"])
+        assert "micro = {:.4f}\nmacro = {:.4f}\nmedian = {:.4f}\n".format(micro, macro, median) == case["stdout"]
+
+
 def test_scoring_matches_numpy_restatement(oracle, golden_dir):
     """orc_predict vs an independent numpy statement of the same documented VW rules.  NOT reference parity:
     no vw binary exists here -> 'parity unpinned'."""
