@@ -4,13 +4,22 @@
     python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
 
 A "step" is one pass of the fused predict kernel over one batch of synthetic fragments that is already resident in
-HBM.  Default workload = BASELINE.json configs[1]: 356 classes, 1M fragments of 200 bp, k=64, row_weight=16,
-numHash=1, both strands (-r), 2^31-slot weight table.  Fragments shard across ranks with no collective
-(SURVEY.md §8e): every rank scores its own batch against its own replica of the table ("weak" scaling).
+HBM.  Headline workload (`value`, every N) = BASELINE.json configs[1]: 356 classes, 1M fragments of 200 bp per GPU,
+k=64, row_weight=16, numHash=1, both strands (-r), 2^31-slot weight table.  Fragments shard across ranks with no
+collective: every rank scores its own batch against its own replica of the table ("weak" scaling).
+
+The same run also times the other BASELINE configs with a few steps each and reports them under `configs` in the same
+JSON line (max over ranks, like the headline):
+  cfg3_1564sp    configs[2]: K=1564, 12.5 M fragments per GPU = the per-GPU share of "100 M fragments over 8 GPUs"
+                 (at --gpus 8 the ranks together score exactly that job in one step)
+  cfg4_numhash4  configs[3]: K=1564, numHash=4 (P=5, F=1370)
+  cfg5_emit      configs[4]: training-feature generation (fragment views into HBM-resident genomes -> hashed features)
+Fragments are generated on the device from a seed (uniform ACGT: a 2-bit packed fragment is 50 random bytes), so set-up
+takes seconds at any size.
 
 Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes per launch / mean launch time measured with
 HIP events on the launch stream; `cpu_baseline` = the CPU oracle (oracle/, a bit-exact C port) timed on this
-box's host cores on a bounded sample of the same batch (rank 0, N=1 only).
+box's host cores on a bounded sample of the headline batch (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -32,10 +41,10 @@ WORKLOADS = {
                        desc="10 classes, 1e4 x 200bp, numHash=1, b=18 (plumbing)"),
     "cfg2_356sp_1M": dict(K=356, n=1_000_000, pattern="patterns_k64_t16_m1_s7.txt", bits=31, mode="predict",
                           desc="356 classes, 1M x 200bp fragments, k=64 t=16 numHash=1, -r, b=31"),
-    "cfg3_1564sp": dict(K=1564, n=500_000, pattern="patterns_k64_t16_m1_s7.txt", bits=31, mode="predict",
-                        desc="1564 classes, 200bp fragments per GPU shard, numHash=1, -r, b=31"),
-    "cfg4_numhash4": dict(K=1564, n=200_000, pattern="patterns_k64_t16_m4_s7.txt", bits=31, mode="predict",
-                          desc="1564 classes, numHash=4 (P=5, F=1370), -r, b=31"),
+    "cfg3_1564sp": dict(K=1564, n=12_500_000, pattern="patterns_k64_t16_m1_s7.txt", bits=31, mode="predict",
+                        desc="1564 classes, 12.5M x 200bp fragments per GPU (= 100M over 8 GPUs), numHash=1, -r, b=31"),
+    "cfg4_numhash4": dict(K=1564, n=1_000_000, pattern="patterns_k64_t16_m4_s7.txt", bits=31, mode="predict",
+                          desc="1564 classes, numHash=4 (P=5, F=1370), 1M x 200bp fragments, -r, b=31"),
     "cfg5_emit": dict(K=1564, n=4_000_000, pattern="patterns_k64_t16_m1_s7.txt", bits=31, mode="emit",
                       desc="training-feature generation: sample 200bp fragments from 1564 HBM-resident genomes (zero-copy views) "
                            "and emit their hashed features, numHash=1, -r"),
@@ -51,34 +60,9 @@ WORKLOADS = {
     "train_1564sp": dict(K=1564, n=50_000, pattern="patterns_k64_t16_m1_s7.txt", bits=31, mode="train", cold=True,
                          desc="native OAA learner, worst case (zeroed table each step): 50k labelled 200bp fragments, 1564 classes"),
 }
-
-
-def make_genomes_and_draws(rank, n, L, K, glen):
-    """Synthetic genomes (uniform ACGT, PCG64 seed 1234) + n fragment draws (position, genome) from the CPython-exact
-    sampler (seed 42+rank) through the C-ABI, like `opal.py frag` (reference opal.py:187-196), in shuffled order
-    (reads arrive in no particular order; opal.py:363 shuffles training batches with the same stream)."""
-    import opal_amd
-    n_genomes = max(K, 8)
-    g = np.random.Generator(np.random.PCG64(1234)).integers(0, 4, size=(n_genomes, glen), dtype=np.uint8)
-    cov = (n * L) / float(n_genomes * glen) * 1.02 + 1e-4
-    rng = opal_amd.Rng(42 + rank)
-    pos, gen = rng.sample_positions([glen] * n_genomes, L, cov)
-    assert len(pos) >= n, (len(pos), n)
-    sel = rng.shuffle_perm(len(pos))[:n].astype(np.int64)
-    return g, pos[sel].astype(np.int64), gen[sel].astype(np.int64)
-
-
-def make_fragments(rank, n, L, K):
-    """Explicit fragment codes [n, L] cut from low-coverage genomes (a metagenomic sample covers its genomes thinly, so
-    weight rows are not re-used between fragments)."""
-    g, pos, gen = make_genomes_and_draws(rank, n, L, K, 1_000_000)
-    codes = np.empty((n, L), dtype=np.uint8)
-    step = 100_000
-    ar = np.arange(L, dtype=np.int64)
-    for s in range(0, n, step):
-        e = min(n, s + step)
-        codes[s:e] = g[gen[s:e, None], pos[s:e, None] + ar[None, :]]
-    return codes
+# what the default run times besides the headline: (workload, steps, warmup), bounded so the whole run stays within minutes
+EXTRA = (("cfg3_1564sp", 2, 1), ("cfg4_numhash4", 3, 1), ("cfg5_emit", 10, 2))
+L_FRAG, KMER = 200, 64
 
 
 def algorithmic_bytes_per_fragment(L, F, K, mode):
@@ -92,6 +76,224 @@ def algorithmic_bytes_per_fragment(L, F, K, mode):
     return math.ceil(L / 4) + 4 * K * (F + 1) + 4             # 2-bit read + (F+1) rows of K floats + class id
 
 
+class Bench:
+    """One rank's engine, its weight table (one copy in HBM, shared by every predict workload) and the process group."""
+
+    def __init__(self, args):
+        import torch
+        import opal_amd
+        self.torch, self.amd, self.args = torch, opal_amd, args
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            if self.world == 1 and args.gpus > 1:
+                sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+            args.gpus = self.world
+        self.dist = None
+        if self.world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:      # launched by torch.distributed.run (also with one rank)
+            import torch.distributed as dist
+            # OPAL_DIST_BACKEND=gloo is for rehearsing the N>1 path on a box with fewer GPUs than ranks (ranks then share
+            # devices round-robin); the driver's runs use nccl (= RCCL), one rank per GPU
+            backend = os.environ.get("OPAL_DIST_BACKEND", "nccl")
+            if backend != "nccl":
+                local_rank = local_rank % torch.cuda.device_count()
+            torch.cuda.set_device(local_rank)
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend=backend)
+            self.dist = dist
+        self.dev = torch.device("cuda", local_rank)
+        self.eng = opal_amd.Engine(local_rank)
+        self.eng.set_vw_options()                      # VW defaults: --hash strings, constant feature, clip to [-1,1]
+        self.table, self.table_bits = None, 0
+
+    def weights(self, bits):
+        """fp32 N(0, 0.05^2) dense table of 2^bits floats, seed 99, same on every rank, generated on the
+        device with room for the row-wrap mirror of the largest K, so that the engine scores it in place (one copy)."""
+        t = self.torch
+        if self.table is None or self.table_bits != bits:
+            self.table = None
+            gen = t.Generator(device=self.dev)
+            gen.manual_seed(99)
+            self.table = t.empty((1 << bits) + 4096, dtype=t.float32, device=self.dev)
+            self.table[:1 << bits].normal_(0.0, 0.05, generator=gen)
+            self.table_bits = bits
+        return self.table
+
+    def device_fragments(self, n, L, seed):
+        """n fragments of L uniform ACGT bases, 2-bit packed (L/4 random bytes each), generated on the device."""
+        t = self.torch
+        nb = (L + 3) // 4
+        gen = t.Generator(device=self.dev)
+        gen.manual_seed(seed)
+        data = t.randint(0, 256, (n * nb,), dtype=t.uint8, device=self.dev, generator=gen)
+        off = t.arange(n, dtype=t.int64, device=self.dev) * (nb * 4)          # packed fragments are addressed in bases
+        ln = t.full((n,), L, dtype=t.int32, device=self.dev)
+        from opal_amd.engine import DeviceBatch
+        return DeviceBatch(data, off, ln, n, n * nb)
+
+    def device_genomes(self, n_genomes, glen, seed):
+        """n_genomes uniform ACGT genomes of glen bases, packed and resident in HBM (generated there)."""
+        from opal_amd.engine import DeviceBatch
+        b = self.device_fragments(n_genomes, glen, seed)
+        host = self.amd.PackedReads(None, np.arange(n_genomes, dtype=np.uint64) * np.uint64(glen), np.full(n_genomes, glen, dtype=np.uint32))
+        return self.amd.GenomeSet(self.eng, host, DeviceBatch(b.data, b.off, b.len, n_genomes, b.nbytes))
+
+    def views(self, gs, n, L, glen, n_genomes):
+        """n fragment draws (position, genome) from the CPython-exact sampler (seed 42+rank) through the C-ABI, like
+        `opal.py frag` (reference opal.py:187-196), in shuffled order (opal.py:363 shuffles with the same stream)."""
+        cov = (n * L) / float(n_genomes * glen) * 1.02 + 1e-4
+        rng = self.amd.Rng(42 + self.rank)
+        pos, gen = rng.sample_positions([glen] * n_genomes, L, cov)
+        assert len(pos) >= n, (len(pos), n)
+        sel = rng.shuffle_perm(len(pos))[:n].astype(np.int64)
+        return gs.fragments(pos[sel], gen[sel], L), gen[sel]
+
+    # ---------------------------------------------------------------------------------------------- one workload
+    def prepare(self, name, wl):
+        """Builds the inputs of a workload in HBM; returns (step, pre_step, info)."""
+        t, eng, dev = self.torch, self.eng, self.dev
+        K, n, bits, mode = wl["K"], wl["n"], wl["bits"], wl["mode"]
+        L, k = L_FRAG, KMER
+        with open(os.path.join(ROOT, "tests", "golden", wl["pattern"])) as f:
+            pos = self.amd.parse_patterns(f.readlines(), k)
+        eng.set_patterns(pos, k)
+        P = pos.shape[0]
+        F = (L - k + 1) * P * 2
+        info = dict(K=K, n=n, bits=bits, mode=mode, P=P, F=F, pos=pos, batch=None, out_class=None)
+        pre_step = None
+        if mode == "predict":
+            eng.adopt_weights(self.weights(bits), K, bits)
+            batch = self.device_fragments(n, L, 1234 + self.rank)
+            out_class = t.empty(n, dtype=t.int32, device=dev)
+            info.update(batch=batch, out_class=out_class, kernel=eng.predict_kernel_name())
+
+            def step():
+                eng.predict(batch, True, want_scores=False, out_class=out_class)
+        elif mode == "emit":
+            n_genomes, glen = max(K, 8), 200_000
+            gs = self.device_genomes(n_genomes, glen, 1234)
+            batch, _ = self.views(gs, n, L, glen, n_genomes)
+            offsets = eng.feature_offsets(batch, True)
+            total = int(offsets[-1].item())
+            out_idx = t.empty(total, dtype=t.int32, device=dev)
+            from opal_amd._lib import check, lib
+            info.update(kernel="emit_idx_kernel", keep=(gs, offsets, out_idx))
+
+            def step():
+                check(lib().opal_features(eng._h, batch.data.data_ptr(), batch.nbytes, batch.off.data_ptr(), batch.len.data_ptr(),
+                                          batch.n, 1, bits, offsets.data_ptr(), out_idx.data_ptr(), total), eng._h)
+        elif mode == "train":
+            n_genomes, glen = max(K, 8), 200_000
+            gs = self.device_genomes(n_genomes, glen, 1234)
+            batch, ggen = self.views(gs, n, L, glen, n_genomes)
+            labels = t.from_numpy((ggen.astype(np.int64) % K + 1).astype(np.int32)).to(dev)
+            eng.train_begin(K, bits)
+            if wl.get("cold"):
+                pre_step = lambda: eng.train_begin(K, bits)   # re-zero w and G outside the timed events
+            info.update(kernel="train_kernel", keep=(gs, labels))
+
+            def step():
+                eng.train_batch(batch, labels, True, eta=0.5)
+        else:   # ingest: ">%08d\n" + 200 bases + "\n" per record, uniform ACGT (PCG64 seed 1234 + rank)
+            rec = np.empty((n, 10 + L + 1), dtype=np.uint8)
+            rec[:, 0] = ord(">")
+            ids = np.arange(n)
+            for d in range(8):
+                rec[:, 8 - d] = ord("0") + (ids // 10 ** d) % 10
+            rec[:, 9] = rec[:, 10 + L] = ord("\n")
+            rec[:, 10:10 + L] = np.frombuffer(b"ACGT", dtype=np.uint8)[
+                np.random.Generator(np.random.PCG64(1234 + self.rank)).integers(0, 4, size=(n, L), dtype=np.uint8)]
+            d_text = t.from_numpy(rec.reshape(-1)).to(dev)
+            nbytes = int(d_text.numel())
+            ing_reads = t.empty(nbytes // 4 + 4096, dtype=t.uint8, device=dev)
+            ing_off = t.empty(n, dtype=t.int64, device=dev)
+            ing_len = t.empty(n, dtype=t.int32, device=dev)
+            import ctypes as C
+            from opal_amd._lib import check, lib
+            c_a, c_b = C.c_uint64(), C.c_uint64()
+            info.update(kernel="ing_summary_kernel + ing_scan_kernel + ing_pack_kernel + ing_records_kernel (whole call)")
+
+            def step():
+                check(lib().opal_ingest_scan(eng._h, d_text.data_ptr(), nbytes, C.byref(c_a), C.byref(c_b)), eng._h)
+                check(lib().opal_ingest_fasta(eng._h, d_text.data_ptr(), nbytes, ing_reads.data_ptr(), ing_reads.numel(), ing_off.data_ptr(),
+                                              ing_len.data_ptr(), n, C.byref(c_a), C.byref(c_b)), eng._h)
+                assert c_a.value == n
+        return step, pre_step, info
+
+    def timed(self, step, pre_step, steps, warmup):
+        """W untimed steps, then exactly `steps` steps between barrier + synchronize on both sides.  Returns (whole-job
+        seconds = max over ranks, per-rank seconds up to the rank's own synchronize, mean launch ms from HIP events)."""
+        t, dev, dist = self.torch, self.dev, self.dist
+        for _ in range(warmup):
+            if pre_step:
+                pre_step()
+            step()
+        t.cuda.synchronize(dev)
+        if dist:
+            dist.barrier()
+        t.cuda.synchronize(dev)
+        ev = [(t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        t_pre = 0.0
+        for a, b in ev:
+            if pre_step:                                   # (learner worst case only) untimed re-zeroing between steps
+                t.cuda.synchronize(dev)
+                tp = time.perf_counter()
+                pre_step()
+                t.cuda.synchronize(dev)
+                t_pre += time.perf_counter() - tp
+            a.record()      # torch's current stream IS the ctx stream (Engine binds to it), so these bracket the kernel
+            step()
+            b.record()
+        t.cuda.synchronize(dev)
+        mine = time.perf_counter() - t0 - t_pre
+        if dist:
+            dist.barrier()
+        t.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0 - t_pre
+        per_rank = [mine]
+        if dist:
+            on = dev if dist.get_backend() == "nccl" else "cpu"
+            tt = t.tensor([elapsed], dtype=t.float64, device=on)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+            got = [t.zeros(1, dtype=t.float64, device=on) for _ in range(self.world)]
+            dist.all_gather(got, t.tensor([mine], dtype=t.float64, device=on))
+            per_rank = [float(x.item()) for x in got]
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        return elapsed, per_rank, kern_ms
+
+    def measure(self, name, wl, steps, warmup, traffic_key):
+        step, pre_step, info = self.prepare(name, wl)
+        elapsed, per_rank, kern_ms = self.timed(step, pre_step, steps, warmup)
+        K, n, mode, F = info["K"], info["n"], info["mode"], info["F"]
+        frag_per_s = self.world * n * steps / elapsed
+        abytes = algorithmic_bytes_per_fragment(L_FRAG, F, K, mode) * n
+        achieved = abytes / (kern_ms * 1e-3) / 1e9
+        prof = {}
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp) and traffic_key:
+            with open(tp) as f:
+                prof = json.load(f).get(traffic_key, {})
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": prof.get("hbm_bytes_per_launch"), "algorithmic_bytes_per_launch": abytes, "kernel_ms": kern_ms}
+        for key in ("valu_issue_frac", "lds_busy_frac"):       # kernels that are ALU/LDS-bound by construction (SURVEY.md §8d):
+            if key in prof:                                    # integer-ALU and LDS utilisation from the committed PMC passes
+                roof[key] = prof[key]
+        res = {"value": frag_per_s, "unit": "fragments/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+               "per_rank_ms_per_step": [x / steps * 1e3 for x in per_rank],
+               "hashes_per_s": None if mode == "ingest" else frag_per_s * F, "kernel": info["kernel"],
+               "dtype": "u8" if mode == "ingest" else "u32" if mode == "emit" else "f32", "roofline": roof,
+               "config": {"workload": name, "desc": wl["desc"], "classes": K, "fragments_per_gpu": n, "frag_len": L_FRAG,
+                          "kmer": KMER, "row_weight": 16, "patterns": info["P"], "reverse_complement": True, "bits": info["bits"],
+                          "features_per_fragment": F,
+                          "parallelism": "fragment-sharded x%d, replicated table, no collective" % self.world}}
+        return res, info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,34 +303,13 @@ def main():
     ap.add_argument("--nfrag", type=int, default=0, help="override fragments per GPU")
     ap.add_argument("--bits", type=int, default=0, help="override table bits")
     ap.add_argument("--classes", type=int, default=0, help="override the class count K (experiments)")
+    ap.add_argument("--no-extra", action="store_true", help="time the headline workload only (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=300_000)
     args = ap.parse_args()
 
-    import torch
-    import opal_amd
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
-    dist = None
-    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:      # launched by torch.distributed.run (also with one rank)
-        import torch.distributed as dist
-        # OPAL_DIST_BACKEND=gloo is for rehearsing the N>1 path on a box with fewer GPUs than ranks (ranks then share
-        # devices round-robin); the driver's runs use nccl (= RCCL), one rank per GPU
-        backend = os.environ.get("OPAL_DIST_BACKEND", "nccl")
-        if backend != "nccl":
-            local_rank = local_rank % torch.cuda.device_count()
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=backend)
-
+    B = Bench(args)
+    overridden = bool(args.nfrag or args.bits or args.classes)
     wl = dict(WORKLOADS[args.workload])
     if args.nfrag:
         wl["n"] = args.nfrag
@@ -136,185 +317,59 @@ def main():
         wl["bits"] = args.bits
     if args.classes:
         wl["K"] = args.classes
-    K, n, bits, mode = wl["K"], wl["n"], wl["bits"], wl["mode"]
-    L, k = 200, 64
-    with open(os.path.join(ROOT, "tests", "golden", wl["pattern"])) as f:
-        pos = opal_amd.parse_patterns(f.readlines(), k)
-    P = pos.shape[0]
-    F = (L - k + 1) * P * 2
 
-    dev = torch.device("cuda", local_rank)
-    eng = opal_amd.Engine(local_rank)
-    eng.set_patterns(pos, k)
-    w = None
-    if mode == "predict":
-        gen = torch.Generator(device=dev)
-        gen.manual_seed(99)
-        w = torch.empty(1 << bits, dtype=torch.float32, device=dev)
-        w.normal_(0.0, 0.05, generator=gen)           # fp32 N(0, 0.05^2) dense table, same on every rank
-        eng.load_weights(w, K, bits)
-        eng.set_vw_options()                            # VW defaults: --hash strings, constant feature, clip to [-1,1]
-    labels = None
-    if mode == "predict":
-        codes = make_fragments(rank, n, L, max(K, 1))
-        batch = eng.upload(opal_amd.PackedReads.from_codes(codes))
-    elif mode == "ingest":
-        # ">%08d\n" + 200 bases + "\n" per record, uniform ACGT (PCG64 seed 1234 + rank)
-        codes = None
-        rec = np.empty((n, 10 + L + 1), dtype=np.uint8)
-        rec[:, 0] = ord(">")
-        ids = np.arange(n)
-        for d in range(8):
-            rec[:, 8 - d] = ord("0") + (ids // 10 ** d) % 10
-        rec[:, 9] = rec[:, 10 + L] = ord("\n")
-        rec[:, 10:10 + L] = np.frombuffer(b"ACGT", dtype=np.uint8)[
-            np.random.Generator(np.random.PCG64(1234 + rank)).integers(0, 4, size=(n, L), dtype=np.uint8)]
-        d_text = torch.from_numpy(rec.reshape(-1)).to(dev)
-        nbytes = int(d_text.numel())
-        ing_reads = torch.empty(nbytes // 4 + 4096, dtype=torch.uint8, device=dev)
-        ing_off = torch.empty(n, dtype=torch.int64, device=dev)
-        ing_len = torch.empty(n, dtype=torch.int32, device=dev)
-    else:
-        # genomes packed once and resident in HBM; a batch is 12 bytes of (offset, length) per fragment
-        g, gpos, ggen = make_genomes_and_draws(rank, n, L, max(K, 1), 200_000)
-        gs = opal_amd.GenomeSet(eng, opal_amd.PackedReads.from_codes(g))
-        batch = gs.fragments(gpos, ggen, L)
-        codes = None
-        labels = torch.from_numpy((ggen % K + 1).astype(np.int32)).to(dev)
-    out_class = torch.empty(n, dtype=torch.int32, device=dev)
-    pre_step = None
-    if mode == "train":
-        eng.set_vw_options()
-        eng.train_begin(K, bits)
-        if wl.get("cold"):
-            pre_step = lambda: eng.train_begin(K, bits)   # re-zero w and G outside the timed events
-
-        def step():
-            eng.train_batch(batch, labels, True, eta=0.5)
-    elif mode == "ingest":
-        import ctypes as C
-        from opal_amd._lib import check, lib
-        c_a, c_b = C.c_uint64(), C.c_uint64()
-
-        def step():
-            check(lib().opal_ingest_scan(eng._h, d_text.data_ptr(), nbytes, C.byref(c_a), C.byref(c_b)), eng._h)
-            check(lib().opal_ingest_fasta(eng._h, d_text.data_ptr(), nbytes, ing_reads.data_ptr(), ing_reads.numel(), ing_off.data_ptr(),
-                                          ing_len.data_ptr(), n, C.byref(c_a), C.byref(c_b)), eng._h)
-            assert c_a.value == n
-    elif mode == "emit":
-        offsets = eng.feature_offsets(batch, True)
-        total = int(offsets[-1].item())
-        out_idx = torch.empty(total, dtype=torch.int32, device=dev)
-        from opal_amd._lib import check, lib
-
-        def step():
-            check(lib().opal_features(eng._h, batch.data.data_ptr(), batch.nbytes, batch.off.data_ptr(), batch.len.data_ptr(),
-                                      batch.n, 1, bits, offsets.data_ptr(), out_idx.data_ptr(), total), eng._h)
-    else:
-        def step():
-            eng.predict(batch, True, want_scores=False, out_class=out_class)
-
-    for _ in range(args.warmup):
-        if pre_step:
-            pre_step()
-        step()
-    torch.cuda.synchronize(dev)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    t_pre = 0.0
-    for a, b in ev:
-        if pre_step:                                   # (learner worst case only) untimed re-zeroing between steps
-            torch.cuda.synchronize(dev)
-            tp = time.perf_counter()
-            pre_step()
-            torch.cuda.synchronize(dev)
-            t_pre += time.perf_counter() - tp
-        a.record()      # torch's current stream IS the ctx stream (Engine binds to it), so these bracket the kernel
-        step()
-        b.record()
-    torch.cuda.synchronize(dev)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0 - t_pre
-    if dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-
-    if rank == 0:
-        frag_per_s = world * n * args.steps / elapsed
-        abytes = algorithmic_bytes_per_fragment(L, F, K, mode) * n
-        achieved = abytes / (kern_ms * 1e-3) / 1e9
-        traffic, prof = None, {}
-        tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
-            with open(tp) as f:
-                prof = json.load(f).get(args.workload if not (args.nfrag or args.bits or args.classes) else "", {})
-                traffic = prof.get("hbm_bytes_per_launch")
-        res = {
-            "metric": "fragments/sec", "value": frag_per_s, "unit": "fragments/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8" if mode == "ingest" else "u32" if mode == "emit" else "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "desc": wl["desc"], "classes": K, "fragments_per_gpu": n, "frag_len": L,
-                       "kmer": k, "row_weight": 16, "patterns": P, "reverse_complement": True, "bits": bits,
-                       "features_per_fragment": F, "parallelism": "fragment-sharded x%d, replicated table, no collective" % world},
-            "hashes_per_s": None if mode == "ingest" else frag_per_s * F,
-            "kernel": {"predict": eng.predict_kernel_name(), "emit": "emit_idx_kernel", "train": "train_kernel",
-                       "ingest": "ing_summary_kernel + ing_scan_kernel + ing_pack_kernel + ing_records_kernel (whole call)"}[mode],
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": abytes, "kernel_ms": kern_ms},
-        }
-        for key in ("valu_issue_frac", "lds_busy_frac"):        # kernels that are ALU/LDS-bound by construction:
-            if key in prof:                                     # integer-ALU and LDS utilisation from the committed PMC passes
-                res["roofline"][key] = prof[key]
+    head, info = B.measure(args.workload, wl, args.steps, args.warmup, None if overridden else args.workload)
+    res = {"metric": "fragments/sec", "value": head["value"], "unit": "fragments/s", "n_gpus": B.world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic (uniform ACGT fragments generated on the device from a seed)",
+           "config": head["config"], "hashes_per_s": head["hashes_per_s"], "kernel": head["kernel"], "roofline": head["roofline"],
+           "per_rank_ms_per_step": head["per_rank_ms_per_step"]}
+    if B.rank == 0:
         import shutil
         res["vw_binary_on_box"] = shutil.which("vw")       # time a real vw if one exists (never seen so far)
-        if world == 1 and not args.no_cpu_baseline and codes is not None:
-            res["cpu_baseline"] = cpu_baseline(codes, pos, k, w, K, bits, mode, min(args.cpu_sample, n), out_class)
+        if B.world == 1 and not args.no_cpu_baseline and info["mode"] == "predict":
+            res["cpu_baseline"] = cpu_baseline(B, info, min(args.cpu_sample, info["n"]))
+    del info
+    if args.workload == "cfg2_356sp_1M" and not overridden and not args.no_extra:
+        res["configs"] = {}
+        for name, steps, warmup in EXTRA:
+            B.torch.cuda.empty_cache()
+            r, inf = B.measure(name, dict(WORKLOADS[name]), steps, warmup, name)
+            del inf
+            res["configs"][name] = r
+    if B.rank == 0:
         print(json.dumps(res), flush=True)
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if B.dist:
+        B.dist.barrier()
+        B.dist.destroy_process_group()
 
 
-def cpu_baseline(codes, pos, k, w, K, bits, mode, m, out_class):
-    """Times the CPU oracle (the checker, a scalar C port with OpenMP over fragments) on the first m fragments."""
+def cpu_baseline(B, info, m):
+    """Times the CPU oracle (the checker, a scalar C port with OpenMP over fragments) on the first m fragments of the
+    batch the GPU just scored, and compares the classes."""
     from oracle import oracle as orc
     orc.build()
-    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
-    L = codes.shape[1]
-    blob = np.ascontiguousarray(acgt[codes[:m]].reshape(-1))
+    L, k, pos, K, bits = L_FRAG, KMER, info["pos"], info["K"], info["bits"]
+    nb = (L + 3) // 4
+    packed = info["batch"].data[:m * nb].cpu().numpy().reshape(m, nb)
+    codes = ((packed[:, :, None] >> (np.arange(4, dtype=np.uint8) * 2)[None, None, :]) & 3).reshape(m, nb * 4)[:, :L]
+    blob = np.ascontiguousarray(np.frombuffer(b"ACGT", dtype=np.uint8)[codes].reshape(-1))
     blob = np.concatenate([blob, np.zeros(1, dtype=np.uint8)])
     soff = np.arange(m + 1, dtype=np.uint64) * np.uint64(L)
     threads = min(16, orc.max_threads())
-    if mode == "emit":
-        t0 = time.perf_counter()
-        idx, off = orc.features_batch((blob, soff), k, pos, True, bits, nthreads=threads)
-        dt = time.perf_counter() - t0
-        ok = None
-    else:
-        wh = w.cpu().numpy()
-        t0 = time.perf_counter()
-        cls, _, _ = orc.predict((blob, soff), k, pos, True, wh, K, bits, want_scores=False, nthreads=threads)
-        dt = time.perf_counter() - t0
-        ok = bool(np.array_equal(cls, out_class[:m].cpu().numpy()))   # the timed GPU output agrees with the checker
-        m1 = max(1000, m // 50)
-        t1 = time.perf_counter()
-        orc.predict((blob[:m1 * L + 1], soff[:m1 + 1]), k, pos, True, wh, K, bits, want_scores=False, nthreads=1)
-        dt1 = time.perf_counter() - t1
-    out = {"value": m / dt, "unit": "fragments/s", "cores": threads, "kind": "port",
-           "sample": "first %d fragments of the same batch, oracle/opal_oracle.c with %d OpenMP threads (%.1f s)" % (m, threads, dt)}
-    if mode != "emit":
-        out["value_1thread"] = m1 / dt1
-        out["gpu_matches_oracle_on_sample"] = ok
-        out["reference_python_1core"] = "3833 frag/s feature half only (BASELINE.md, survey container); vw absent"
-    return out
+    wh = B.table[:1 << bits].cpu().numpy()
+    t0 = time.perf_counter()
+    cls, _, _ = orc.predict((blob, soff), k, pos, True, wh, K, bits, want_scores=False, nthreads=threads)
+    dt = time.perf_counter() - t0
+    ok = bool(np.array_equal(cls, info["out_class"][:m].cpu().numpy()))   # the timed GPU output agrees with the checker
+    m1 = max(1000, m // 50)
+    t1 = time.perf_counter()
+    orc.predict((blob[:m1 * L + 1], soff[:m1 + 1]), k, pos, True, wh, K, bits, want_scores=False, nthreads=1)
+    dt1 = time.perf_counter() - t1
+    return {"value": m / dt, "unit": "fragments/s", "cores": threads, "kind": "port",
+            "sample": "first %d fragments of the same batch, oracle/opal_oracle.c with %d OpenMP threads (%.1f s)" % (m, threads, dt),
+            "value_1thread": m1 / dt1, "gpu_matches_oracle_on_sample": ok,
+            "reference_python_1core": "3833 frag/s feature half only (BASELINE.md, survey container); vw absent"}
 
 
 if __name__ == "__main__":

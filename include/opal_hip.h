@@ -67,6 +67,18 @@ int opal_set_patterns(opal_ctx *ctx, const int32_t *pos, int P, int t, int k);
 int opal_load_weights(opal_ctx *ctx, const float *w, uint64_t n_slots, int K, int bits);
 int opal_set_weights_device(opal_ctx *ctx, const float *d_w, uint64_t n_slots, int K, int bits);
 
+/* Like opal_set_weights_device without the second copy: the ctx scores straight from the caller's buffer, which must
+ * stay alive and unchanged while the ctx uses it and must hold capacity_floats >= n_slots + K + 4 floats, 16-byte
+ * aligned.  The call writes the mirror of the table's first K+4 floats into [n_slots, n_slots+K+4) (rows then never
+ * wrap); the ctx never frees or grows the buffer.  An 8 GiB model is resident once.  (opal.py:449-451, as above)     */
+int opal_adopt_weights_device(opal_ctx *ctx, float *d_w, uint64_t n_slots, uint64_t capacity_floats, int K, int bits);
+
+/* Tuning knobs for tests and experiments (the defaults are the production settings; the library reads no environment
+ * variables).  predict_nt: -1 = row-load cache policy by table size (non-temporal from 4 GiB), 0 = default loads,
+ * 1 = non-temporal loads.  emit_qchunk: fragments per work-queue draw of opal_features (at most 64), 0 = default (32).
+ * emit_fast: 1 = opal_features hashes short 2-bit packed fragments with its fast kernel (default), 0 = generic kernel only. */
+int opal_set_tuning(opal_ctx *ctx, int predict_nt, uint64_t emit_qchunk, int emit_fast);
+
 /* VW behaviours that differ between versions, defaults in brackets:
  * hash_all [0]: 0 = `--hash strings` (all-digit names are read as numbers), 1 = `--hash all`;
  * add_constant [1]: append the bias feature 11650396 after the user features;

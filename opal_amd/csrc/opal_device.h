@@ -28,7 +28,17 @@ struct Geom {
     int reverse;
     int hash_all;
     int p0_run;   // >= 0: pattern 0 is the ascending run p0_run, p0_run+1, ... (Opal's first row is 0..t-1); -1 otherwise
+    int fast_canon2;        // emit fast path: P == 2, pattern 0 a run of 16 positions, pattern 1 gathered
+    const uint32_t *fast;   // emit fast path (t == 16, positions ascending inside every block of 4): FASTPAT_DW dwords per pattern, else nullptr
 };
+
+// Per-pattern record of the emit fast path (built by opal_set_patterns), FASTPAT_DW dwords:
+//   [0..15] 4 * (pos_j - (j & 3)): the byte offset, inside a window's slice of the per-base array Z of emit_fast, of the
+//           word that holds the code of pos_j at bits 2+2(j&3)
+//   [16]    murmur term of the decimal pattern index xor the name length (wave-uniform tail of every name of the pattern)
+//   [17]    0xf when the 16 positions are one run of consecutive positions, else 0
+//   [18]    4 * (pos_0 + 1): for a run, the offset of the one word that holds all 16 codes
+constexpr int FASTPAT_DW = 20;
 
 // ------------------------------------------------------------------------------------------ byte helpers
 __device__ __forceinline__ uint32_t rc_byte(uint32_t c)

@@ -13,10 +13,13 @@ struct opal_ctx {
     // patterns (util/fasta2skm.py:120-134)
     int k = 0, P = 0, t = 0;
     uint8_t *d_pos = nullptr;  // P*t positions, each < k <= 256
+    uint32_t *d_fast = nullptr; // per-pattern records of the emit fast path (FASTPAT_DW dwords each), nullptr when the geometry has none
+    bool fast_canon2 = false;   // P == 2, pattern 0 a run of 16, pattern 1 gathered: the emit kernel's straight-line step
     int p0_run = -1;           // first position of pattern 0 when it is a run of consecutive positions, else -1
     // weights (VW regressor, compact `w` components)
     float *d_w = nullptr;      // 2^bits + pad floats: first K(+3) floats mirrored at the end so rows never wrap
     uint64_t w_alloc_floats = 0;
+    bool w_owned = true;       // false: d_w is the caller's buffer (opal_adopt_weights_device), never freed or grown here
     float *d_g2 = nullptr;     // trainer: AdaGrad accumulators, 2^bits floats (canonical slots only)
     uint64_t g2_alloc_floats = 0;
     bool g2_valid = false;
@@ -25,6 +28,10 @@ struct opal_ctx {
     // VW switches
     int hash_all = 0, add_constant = 1, clip = 1;
     float min_label = -1.0f, max_label = 1.0f;
+    // tuning (opal_set_tuning): predict row-load policy -1 = by table size, 0 = default loads, 1 = non-temporal; emit draw size 0 = default
+    int tune_nt = -1;
+    uint64_t tune_qchunk = 0;
+    bool tune_emit_fast = true;   // false: opal_features uses the generic kernel only (tests compare the two)
     // scratch for the offsets scan
     unsigned long long *d_queue = nullptr;   // work-queue counter of the predict kernel (allocated with the ctx)
     uint64_t *d_block_sums = nullptr;
@@ -41,6 +48,11 @@ struct opal_ctx {
 
 namespace opal {
 int fail(opal_ctx *ctx, int code, const std::string &msg);
+// forgets a table the ctx does not own, so that the allocation paths below start from "no table"
+inline void drop_adopted_table(opal_ctx *ctx)
+{
+    if (!ctx->w_owned) { ctx->d_w = nullptr; ctx->w_alloc_floats = 0; ctx->w_owned = true; }
+}
 }  // namespace opal
 
 #define OPAL_HIP_CHECK(ctx, call)                                                                              \

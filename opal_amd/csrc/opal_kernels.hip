@@ -39,36 +39,415 @@ __device__ __forceinline__ uint64_t feature_count(uint32_t len_word, const Geom 
 constexpr int HB_EMIT = 640;
 constexpr uint64_t EMIT_QCHUNK = 32;   // fragments per draw from the work queue: a fragment takes ~10 us here (100x less than in predict) and the
                                        // counter is one address: 8 per draw = 83 M atomics/s held the kernel at 6.14 ms, 16-32 give 5.26, 256 5.65 (tail)
-__global__ __launch_bounds__(BLOCK) void emit_idx_kernel(Batch B, Geom G, uint32_t mask, const uint64_t *__restrict__ out_off,
-                                                          uint32_t *__restrict__ out_idx, uint64_t out_cap,
-                                                          unsigned long long *__restrict__ queue, uint64_t qchunk)
+
+// ---- emit fast path: 2-bit packed fragments of at most EF_MAXLEN bases, t = 16, positions ascending inside each block of 4.
+// The r01 kernel spent its time in VALU issue (96 %) and in the LDS (72 % busy): per hash 16 byte gathers with an address
+// add each, 12 shift-ors to build the four table indices, and a hash buffer written and read back.  Here a wave builds,
+// per strand, ONE dword per base: Z[i] = the 16 codes i-1 .. i+14 (32 bits of the packed strand from bit 2i-2), so that
+//   * the code of base i+j sits at bits 2+2j of Z[i]: the j-th letter of a gathered block is taken from Z[pos_j - j] under
+//     the mask 3 << (2+2j), and the four masked words or-ed together ARE the block's byte offset into the 256-entry table
+//     (4 VALU instructions per block instead of 7 + 4 address adds);
+//   * Z[i+1] holds the codes i .. i+15: a pattern that is a run of 16 consecutive positions (Opal's pattern 0) gets all
+//     four table offsets from ONE read (byte b of the word, times 4).
+// Lanes own consecutive windows, so every gather is `ds_read_addtid_b32` (address = M0 + 4*lane, no address VGPR, no
+// VALU): the wave-uniform part (window step + pattern position) goes through M0 on the scalar unit.  Hashes go straight
+// from registers to HBM (lane u writes features u*P .. u*P+P-1: contiguous across the wave), no LDS hash buffer.
+constexpr int EF_MAXLEN = 256;           // bases per strand
+constexpr int EF_ZLEN = EF_MAXLEN + 64;  // Z dwords per strand: lanes past the last window read (and discard) up to 63 entries further
+constexpr int EF_PKLEN = 24;             // packed dwords per strand: one zero dword in front (Z[0] starts 2 bits before base 0), 17 of data, slack
+                                         // (the Z build reads up to entry 21: whole iterations of 64)
+constexpr int EF_WAVE_BYTES = 2 * SEQB + HB_EMIT * 4;   // per-wave LDS of the generic kernel (strands + hash buffer)
+
+// Reads Z[lane + (base + q_i)/4] for wave-uniform byte offsets.  M0 is written one instruction before the read that uses it
+// (the ISA asks for one wait state between an SALU write of M0 and an LDS "add-TID" instruction): the add that forms the
+// next address is that instruction, so a gather costs two scalar instructions and no vector one.
+__device__ __forceinline__ uint32_t zread1(uint32_t base, uint32_t q0)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_seq[WPB][2 * SEQB];
-    __shared__ __attribute__((aligned(16))) uint32_t s_hb[WPB][HB_EMIT];
+    uint32_t x, t;
+    asm volatile("s_add_u32 %1, %2, %3\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tds_read_addtid_b32 %0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(x), "=&s"(t) : "s"(base), "s"(q0) : "memory", "scc");
+    return x;
+}
+__device__ __forceinline__ void zread4(uint32_t base, uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3, uint32_t (&x)[4])
+{
+    uint32_t t0, t1;
+    asm volatile("s_add_u32 %4, %6, %7\n\ts_mov_b32 m0, %4\n\t"
+                 "s_add_u32 %5, %6, %8\n\tds_read_addtid_b32 %0\n\ts_mov_b32 m0, %5\n\t"
+                 "s_add_u32 %4, %6, %9\n\tds_read_addtid_b32 %1\n\ts_mov_b32 m0, %4\n\t"
+                 "s_add_u32 %5, %6, %10\n\tds_read_addtid_b32 %2\n\ts_mov_b32 m0, %5\n\t"
+                 "s_nop 0\n\tds_read_addtid_b32 %3\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&s"(t0), "=&s"(t1)
+                 : "s"(base), "s"(q0), "s"(q1), "s"(q2), "s"(q3) : "memory", "scc");
+}
+__device__ __forceinline__ void zread8(uint32_t base, const uint32_t (&q)[8], uint32_t (&x)[8])
+{
+    uint32_t t0, t1;
+    asm volatile("s_add_u32 %8, %10, %11\n\ts_mov_b32 m0, %8\n\t"
+                 "s_add_u32 %9, %10, %12\n\tds_read_addtid_b32 %0\n\ts_mov_b32 m0, %9\n\t"
+                 "s_add_u32 %8, %10, %13\n\tds_read_addtid_b32 %1\n\ts_mov_b32 m0, %8\n\t"
+                 "s_add_u32 %9, %10, %14\n\tds_read_addtid_b32 %2\n\ts_mov_b32 m0, %9\n\t"
+                 "s_add_u32 %8, %10, %15\n\tds_read_addtid_b32 %3\n\ts_mov_b32 m0, %8\n\t"
+                 "s_add_u32 %9, %10, %16\n\tds_read_addtid_b32 %4\n\ts_mov_b32 m0, %9\n\t"
+                 "s_add_u32 %8, %10, %17\n\tds_read_addtid_b32 %5\n\ts_mov_b32 m0, %8\n\t"
+                 "s_add_u32 %9, %10, %18\n\tds_read_addtid_b32 %6\n\ts_mov_b32 m0, %9\n\t"
+                 "s_nop 0\n\tds_read_addtid_b32 %7\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]),
+                   "=&s"(t0), "=&s"(t1)
+                 : "s"(base), "s"(q[0]), "s"(q[1]), "s"(q[2]), "s"(q[3]), "s"(q[4]), "s"(q[5]), "s"(q[6]), "s"(q[7]) : "memory", "scc");
+}
+// zread1 + zread8 in one batch (the canonical two-pattern step: pattern 0's one word and the first half of pattern 1's gathers)
+__device__ __forceinline__ void zread9(uint32_t base, uint32_t r, const uint32_t (&q)[8], uint32_t &xr, uint32_t (&x)[8])
+{
+    uint32_t t0, t1;
+    asm volatile("s_add_u32 %9, %11, %12\n\ts_mov_b32 m0, %9\n\t"
+                 "s_add_u32 %10, %11, %13\n\tds_read_addtid_b32 %0\n\ts_mov_b32 m0, %10\n\t"
+                 "s_add_u32 %9, %11, %14\n\tds_read_addtid_b32 %1\n\ts_mov_b32 m0, %9\n\t"
+                 "s_add_u32 %10, %11, %15\n\tds_read_addtid_b32 %2\n\ts_mov_b32 m0, %10\n\t"
+                 "s_add_u32 %9, %11, %16\n\tds_read_addtid_b32 %3\n\ts_mov_b32 m0, %9\n\t"
+                 "s_add_u32 %10, %11, %17\n\tds_read_addtid_b32 %4\n\ts_mov_b32 m0, %10\n\t"
+                 "s_add_u32 %9, %11, %18\n\tds_read_addtid_b32 %5\n\ts_mov_b32 m0, %9\n\t"
+                 "s_add_u32 %10, %11, %19\n\tds_read_addtid_b32 %6\n\ts_mov_b32 m0, %10\n\t"
+                 "s_add_u32 %9, %11, %20\n\tds_read_addtid_b32 %7\n\ts_mov_b32 m0, %9\n\t"
+                 "s_nop 0\n\tds_read_addtid_b32 %8\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(xr), "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]),
+                   "=&s"(t0), "=&s"(t1)
+                 : "s"(base), "s"(r), "s"(q[0]), "s"(q[1]), "s"(q[2]), "s"(q[3]), "s"(q[4]), "s"(q[5]), "s"(q[6]), "s"(q[7]) : "memory", "scc");
+}
+// the block's table offset from the four words that hold its letters at bits 2-3, 4-5, 6-7, 8-9 (v_and + 3 v_and_or)
+// (left to the compiler the same expression takes 5 instructions: three v_and, one v_and_or, one v_or3)
+__device__ __forceinline__ uint32_t and_or(uint32_t x, uint32_t m, uint32_t acc)   // (x & m) | acc, m wave-uniform
+{
+    uint32_t d;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "s"(m), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ uint32_t block_addr(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3)
+{
+    return and_or(x3, 0x300u, and_or(x2, 0xc0u, and_or(x1, 0x30u, x0 & 0xcu)));
+}
+__device__ __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// One step of 64 windows (flat index u0 + lane over the forward strand's W windows, then the reverse complement's).
+// MODE 0: every lane is on the forward strand, 1: on the reverse strand, 2: the step straddles the two (at most one step
+// per fragment): every gather is then made for both strands and picked per lane.
+template <int MODE>
+__device__ __forceinline__ void emit_fast_step(const uint32_t *__restrict__ fast, int P, uint32_t zf, uint32_t zr, uint32_t u0,
+                                               uint32_t W, uint32_t U, uint32_t mask, const uint32_t *tab, int lane,
+                                               uint32_t *__restrict__ dst, bool pair_store)
+{
+    const uint32_t u = u0 + (uint32_t)lane;
+    const bool live = u < U;
+    const bool on_rc = u >= W;
+    const uint32_t bf = zf + u0 * 4u;                  // forward: Z_f[u + q]
+    const uint32_t br = zr + (u0 - W) * 4u;            // reverse: Z_r[u - W + q] (for lanes before W it points into Z_f's slack: discarded)
+    const uint32_t b0 = MODE == 1 ? br : bf;
+    auto rd4 = [&](uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3, uint32_t (&x)[4]) {
+        if constexpr (MODE != 2) {
+            zread4(b0, q0, q1, q2, q3, x);
+        } else {
+            uint32_t y[4];
+            zread4(bf, q0, q1, q2, q3, x);
+            zread4(br, q0, q1, q2, q3, y);
+#pragma unroll
+            for (int i = 0; i < 4; i++) x[i] = on_rc ? y[i] : x[i];
+        }
+    };
+    const char *tabc = reinterpret_cast<const char *>(tab);
+    uint32_t h_prev = 0;
+    for (int p = 0; p < P; p++) {
+        // the pattern's record through the scalar cache (constant address space: the kernel never writes it), straight
+        // into SGPRs; as a plain global load it became a vector load + a v_readfirstlane per word, per pattern and step
+        typedef const uint32_t __attribute__((address_space(4))) *const_u32;
+        const const_u32 fp = (const_u32)(uintptr_t)(fast + p * FASTPAT_DW);
+        const uint32_t tail = fp[16];
+        const uint32_t runs = fp[17];
+        uint32_t a[4];
+        if (runs == 0xfu) {                            // a run of 16 consecutive positions (Opal's pattern 0): one read
+            const uint32_t rq = fp[18];
+            uint32_t x = zread1(b0, rq);
+            if constexpr (MODE == 2) { const uint32_t y = zread1(br, rq); x = on_rc ? y : x; }
+#pragma unroll
+            for (int b = 0; b < 4; b++) a[b] = ((x >> (8 * b)) & 0xffu) << 2;
+        } else if (runs == 0u && MODE != 2) {          // an LDPC row: 16 gathers in two batches
+            uint32_t x[8];
+#pragma unroll
+            for (int hb2 = 0; hb2 < 2; hb2++) {
+                uint32_t q[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) q[i] = fp[8 * hb2 + i];
+                zread8(b0, q, x);
+                a[2 * hb2] = block_addr(x[0], x[1], x[2], x[3]);
+                a[2 * hb2 + 1] = block_addr(x[4], x[5], x[6], x[7]);
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                uint32_t x[4];
+                rd4(fp[4 * b], fp[4 * b + 1], fp[4 * b + 2], fp[4 * b + 3], x);
+                a[b] = block_addr(x[0], x[1], x[2], x[3]);     // for a run block the four reads hit the same word: still right
+            }
+        }
+        // a[b] has bits 2..9 only.  Lanes past the last window may have picked up stale words: their hashes are never stored.
+        uint32_t h = *reinterpret_cast<const uint32_t *>(tabc + 1024 + a[0]);   // the hash after the first block
+#pragma unroll
+        for (int b = 1; b < 4; b++) h = mm_hk(h, *reinterpret_cast<const uint32_t *>(tabc + a[b]));
+        h = mm_fmix(h ^ tail) & mask;
+        if (pair_store) {                              // P == 2, 8-byte aligned: one global_store_dwordx2 per lane
+            if (p == 0) h_prev = h;
+            else if (live) *reinterpret_cast<uint2 *>(dst + 2u * u) = make_uint2(h_prev, h);
+        } else if (live) {
+            dst[u * (uint32_t)P + (uint32_t)p] = h;
+        }
+    }
+}
+
+// Stages one fragment (2-bit packed, len <= EF_MAXLEN, its dwords inside the buffer) as the per-base arrays Z_f, Z_r.
+__device__ __forceinline__ void emit_stage(const Batch &B, const Geom &G, uint64_t off, uint32_t len, uint32_t *zw, int lane)
+{
+    uint32_t *zf = zw, *zr = zw + EF_ZLEN, *pkf = zw + 2 * EF_ZLEN, *pkr = pkf + EF_PKLEN;
+    const uint32_t *__restrict__ R32 = reinterpret_cast<const uint32_t *>(B.reads);
+    const uint64_t nd = B.reads_bytes >> 2;
+    const uint64_t a0 = off >> 4;
+    const uint32_t sh = (uint32_t)(off & 15u) * 2u;
+    const uint32_t S = G.reverse ? 2u : 1u;
+    // the fragment's bases as packed dwords behind one zero dword: base 0 of the fragment at bit 0 of pkf[1]
+    if (lane < EF_PKLEN) {
+        uint32_t v = 0;
+        if (lane > 0) {
+            const uint32_t lo = R32[min(a0 + (uint64_t)lane - 1u, nd - 1)], hi = R32[min(a0 + (uint64_t)lane, nd - 1)];
+            v = __builtin_amdgcn_alignbit(hi, lo, sh);
+        }
+        pkf[lane] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (S == 2 && lane < EF_PKLEN) {
+        // reverse complement, packed: dword m = comp(codes len-1-16m .. len-16-16m): the 32 forward bits at base len-16-16m
+        // with the order of their 2-bit groups reversed (v_bfrev + swap inside the pairs) and complemented
+        uint32_t v = 0;
+        if (lane > 0) {
+            const int s = (int)len - 16 * lane;             // m = lane - 1
+            uint32_t x = 0;
+            if (s >= 0) x = __builtin_amdgcn_alignbit(pkf[(s >> 4) + 2], pkf[(s >> 4) + 1], (uint32_t)(s & 15) * 2u);
+            else if (s > -16) x = pkf[1] << (uint32_t)(-s * 2);
+            const uint32_t y = __builtin_bitreverse32(x);
+            v = ~(((y & 0x55555555u) << 1) | ((y >> 1) & 0x55555555u));
+        }
+        pkr[lane] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // Z[i] = 32 bits of the strand from bit 2i-2, for i = lane + 64 it (Z[len] serves run patterns; the entries of the last
+    // iteration that lie past it are never used).  64 entries are 4 packed dwords further on, so the funnel shift is the
+    // same in every iteration and all LDS addresses are one per-lane base + immediates: one VALU instruction per 64 entries.
+    {
+        const uint32_t bo = 2u * (uint32_t)lane + 30u, b = bo & 31u;
+        const uint32_t *pf = pkf + (bo >> 5), *pr = pkr + (bo >> 5);
+        uint32_t *zfl = zf + lane, *zrl = zr + lane;
+#pragma unroll
+        for (int it = 0; it < EF_MAXLEN / WAVE + 1; it++) {
+            if ((uint32_t)(it * WAVE) > len) break;
+            zfl[it * WAVE] = __builtin_amdgcn_alignbit(pf[4 * it + 1], pf[4 * it], b);
+            if (S == 2) zrl[it * WAVE] = __builtin_amdgcn_alignbit(pr[4 * it + 1], pr[4 * it], b);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Hashes fragment `frag` (2-bit packed, k <= len <= EF_MAXLEN, its dwords inside the buffer) into dst[0 .. S*W*P).
+__device__ __forceinline__ void emit_fast(const Batch &B, const Geom &G, uint64_t off, uint32_t len, uint32_t mask, uint32_t *zw,
+                                          const uint32_t *tab, int lane, uint32_t *__restrict__ dst)
+{
+    emit_stage(B, G, off, len, zw, lane);
+    uint32_t *zf = zw, *zr = zw + EF_ZLEN;
+    const uint32_t S = G.reverse ? 2u : 1u;
+    const uint32_t W = len - (uint32_t)G.k + 1u, U = S * W;
+    const uint32_t zfa = sgpr((uint32_t)(uintptr_t)zf), zra = sgpr((uint32_t)(uintptr_t)zr);
+    const bool pair_store = G.P == 2 && (reinterpret_cast<uintptr_t>(dst) & 7u) == 0;
+    for (uint32_t u0 = 0; u0 < U; u0 += WAVE) {
+        if (u0 + WAVE <= W || S == 1) emit_fast_step<0>(G.fast, G.P, zfa, zra, u0, W, U, mask, tab, lane, dst, pair_store);
+        else if (u0 >= W) emit_fast_step<1>(G.fast, G.P, zfa, zra, u0, W, U, mask, tab, lane, dst, pair_store);
+        else emit_fast_step<2>(G.fast, G.P, zfa, zra, u0, W, U, mask, tab, lane, dst, pair_store);
+    }
+    // the next fragment's staging writes must not overtake this fragment's reads (same wave: LDS ops retire in order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Which fragments the fast kernel takes: 2-bit packed, k <= len <= EF_MAXLEN, and every dword the staging needs inside
+// the buffer (locate_fragment's rule for the fragment itself; fragments in the buffer's last, partial dword go the generic way).
+__device__ __forceinline__ bool emit_fast_takes(const Batch &B, const Geom &G, uint32_t lw, uint64_t off)
+{
+    return !(lw & OPAL_RAW_FLAG) && lw >= (uint32_t)G.k && lw <= (uint32_t)EF_MAXLEN && ((off + lw + 3) >> 2) <= B.reads_bytes &&
+           ((off + lw + 15) >> 4) <= (B.reads_bytes >> 2);
+}
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int l)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// ---- The canonical Opal geometry with numHash = 1 (ldpc.py: pattern 0 = a run of 16 positions, pattern 1 = one LDPC row;
+// P = 2, output 8-byte aligned) has a kernel of its own: the two pattern records live in SGPRs for the whole kernel, a step
+// is straight-line code (no pattern loop, no per-pattern dispatch), and the LDS round trips of the two patterns overlap:
+// pattern 0's word travels with the first half of pattern 1's gathers, the first six table reads with the second half.
+// MIXED: the one step per fragment whose lanes straddle the two strands reads both and picks per lane.
+template <bool MIXED>
+__device__ __forceinline__ void canon2_step(uint32_t bf, uint32_t br, bool on_rc, uint32_t rq, const uint32_t (&q)[16], uint32_t tail0,
+                                            uint32_t tail1, uint32_t u, bool live, uint32_t mask, const uint32_t *tab,
+                                            uint32_t *__restrict__ dst)
+{
+    const char *tabc = reinterpret_cast<const char *>(tab);
+    // (tried: pattern 1's four lookups from a copy of the table in global memory, through the otherwise idle L1, to take
+    // them off the LDS: 3.97 -> 4.93 ms; a 64-lane dword gather costs the vector cache far more than the LDS's conflicts)
+    auto T = [&](uint32_t a) { return *reinterpret_cast<const uint32_t *>(tabc + a); };
+    uint32_t x[8], x0;
+    const uint32_t qa[8] = {q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7]};
+    const uint32_t qb[8] = {q[8], q[9], q[10], q[11], q[12], q[13], q[14], q[15]};
+    zread9(bf, rq, qa, x0, x);
+    if constexpr (MIXED) {
+        uint32_t y[8], y0;
+        zread9(br, rq, qa, y0, y);
+        x0 = on_rc ? y0 : x0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = on_rc ? y[i] : x[i];
+    }
+    uint32_t a0[4], a1[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) a0[b] = ((x0 >> (8 * b)) & 0xffu) << 2;
+    a1[0] = block_addr(x[0], x[1], x[2], x[3]);
+    a1[1] = block_addr(x[4], x[5], x[6], x[7]);
+    const uint32_t t00 = T(1024u + a0[0]), t01 = T(a0[1]), t02 = T(a0[2]), t03 = T(a0[3]);
+    const uint32_t t10 = T(1024u + a1[0]), t11 = T(a1[1]);
+    zread8(bf, qb, x);
+    if constexpr (MIXED) {
+        uint32_t y[8];
+        zread8(br, qb, y);
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = on_rc ? y[i] : x[i];
+    }
+    a1[2] = block_addr(x[0], x[1], x[2], x[3]);
+    a1[3] = block_addr(x[4], x[5], x[6], x[7]);
+    const uint32_t t12 = T(a1[2]), t13 = T(a1[3]);
+    const uint32_t h0 = mm_fmix(mm_hk(mm_hk(mm_hk(t00, t01), t02), t03) ^ tail0) & mask;
+    const uint32_t h1 = mm_fmix(mm_hk(mm_hk(mm_hk(t10, t11), t12), t13) ^ tail1) & mask;
+    if (live) *reinterpret_cast<uint2 *>(dst + 2u * u) = make_uint2(h0, h1);
+}
+
+__global__ __launch_bounds__(BLOCK) void emit_canon2_kernel(Batch B, Geom G, uint32_t mask, const uint64_t *__restrict__ out_off,
+                                                             uint32_t *__restrict__ out_idx, uint64_t out_cap,
+                                                             unsigned long long *__restrict__ queue, uint64_t qchunk)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_wave[WPB][2 * EF_ZLEN + 2 * EF_PKLEN];
     __shared__ uint32_t s_tab[KTAB];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = threadIdx.x / WAVE;
     fill_kmer4_table(s_tab);
-    for (uint64_t q0 = next_chunk(queue, lane, qchunk); q0 < B.n; q0 = next_chunk(queue, lane, qchunk))
-    for (uint64_t frag = q0; frag < min(q0 + qchunk, B.n); frag++) {
-        const uint64_t o0 = out_off[frag];
-        if (o0 > out_cap || feature_count(B.len[frag], G) > out_cap - o0) continue;   // never write outside out_idx
-        uint32_t *dst = out_idx + o0;
-        uint32_t *hb = s_hb[wv];
-        walk_fragment<HB_EMIT>(B, G, frag, mask, false, 0u, s_seq[wv], hb, s_tab, lane, [&](uint32_t cnt) {
-            if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {   // wave-uniform: 16-byte stores, then the tail
-                const uint32_t n4 = cnt / 4u;
-                for (uint32_t i = lane; i < n4; i += WAVE)
-                    reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(hb)[i];
-                for (uint32_t i = n4 * 4u + lane; i < cnt; i += WAVE) dst[i] = hb[i];
-            } else {
-                for (uint32_t i = lane; i < cnt; i += WAVE) dst[i] = hb[i];
+    typedef const uint32_t __attribute__((address_space(4))) *const_u32;
+    const const_u32 f0 = (const_u32)(uintptr_t)G.fast, f1 = (const_u32)(uintptr_t)(G.fast + FASTPAT_DW);
+    uint32_t q[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) q[i] = f1[i];
+    const uint32_t rq = f0[18], tail0 = f0[16], tail1 = f1[16];
+    uint32_t *zw = s_wave[wv];
+    const uint32_t zfa = sgpr((uint32_t)(uintptr_t)zw), zra = zfa + EF_ZLEN * 4u;
+    const uint32_t S = G.reverse ? 2u : 1u;
+    unsigned long long left = 0;
+    for (uint64_t q0 = next_chunk(queue, lane, qchunk); q0 < B.n; q0 = next_chunk(queue, lane, qchunk)) {
+        const uint64_t mine = q0 + (uint64_t)lane;
+        uint64_t o0 = 0, off = 0;
+        uint32_t lw = 0;
+        bool take = false;
+        if ((uint64_t)lane < qchunk && mine < B.n) {
+            o0 = out_off[mine];
+            lw = B.len[mine];
+            off = B.off[mine];
+            const bool fits = !(o0 > out_cap || feature_count(lw, G) > out_cap - o0);   // never write outside out_idx
+            take = fits && emit_fast_takes(B, G, lw, off);
+            if (fits && !take) left++;
+        }
+        for (uint64_t todo = __ballot(take); todo; todo &= todo - 1) {
+            const int i = __builtin_ctzll(todo);
+            uint32_t *dst = out_idx + readlane64(o0, i);
+            const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)lw, i);
+            emit_stage(B, G, readlane64(off, i), len, zw, lane);
+            const uint32_t W = len - (uint32_t)G.k + 1u, U = S * W;
+            for (uint32_t u0 = 0; u0 < U; u0 += WAVE) {
+                const uint32_t u = u0 + (uint32_t)lane;
+                const uint32_t bf = zfa + u0 * 4u, br = zra + (u0 - W) * 4u;
+                if (u0 + WAVE <= W || S == 1) canon2_step<false>(bf, 0u, false, rq, q, tail0, tail1, u, u < U, mask, s_tab, dst);
+                else if (u0 >= W) canon2_step<false>(br, 0u, false, rq, q, tail0, tail1, u, u < U, mask, s_tab, dst);
+                else canon2_step<true>(bf, br, u >= W, rq, q, tail0, tail1, u, u < U, mask, s_tab, dst);
             }
-            dst += cnt;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next fragment's staging stays behind these reads
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        });
+        }
     }
+    if (left) atomicAdd(queue + 2, left);
+}
+
+// The two emit kernels share one work loop: a wave draws qchunk (<= 64) consecutive fragments, every lane looks at one of
+// them (inside out_cap? the fast kernel's kind or the generic kernel's?), and the wave then walks the selected ones.
+// FAST = true: emit_fast for the fragments emit_fast_takes() accepts; counts the others in queue[2].
+// FAST = false: the generic walker for every fragment (fast_ran == 0) or for those the fast kernel left (fast_ran != 0;
+// it returns at once when that kernel left none).
+template <bool FAST>
+__global__ __launch_bounds__(BLOCK) void emit_idx_kernel(Batch B, Geom G, uint32_t mask, const uint64_t *__restrict__ out_off,
+                                                          uint32_t *__restrict__ out_idx, uint64_t out_cap,
+                                                          unsigned long long *__restrict__ queue, uint64_t qchunk, int fast_ran)
+{
+    constexpr int WAVE_BYTES = FAST ? (2 * EF_ZLEN + 2 * EF_PKLEN) * 4 : EF_WAVE_BYTES;
+    __shared__ __attribute__((aligned(16))) uint8_t s_wave[WPB][WAVE_BYTES];
+    __shared__ uint32_t s_tab[KTAB];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wv = threadIdx.x / WAVE;
+    if (!FAST && fast_ran && __builtin_nontemporal_load(queue + 2) == 0ull) return;   // block-uniform: nothing was left over
+    fill_kmer4_table(s_tab);
+    unsigned long long left = 0;
+    for (uint64_t q0 = next_chunk(queue + (FAST ? 0 : 1), lane, qchunk); q0 < B.n; q0 = next_chunk(queue + (FAST ? 0 : 1), lane, qchunk)) {
+        const uint64_t mine = q0 + (uint64_t)lane;
+        uint64_t o0 = 0, off = 0;
+        uint32_t lw = 0;
+        bool take = false;
+        if ((uint64_t)lane < qchunk && mine < B.n) {
+            o0 = out_off[mine];
+            lw = B.len[mine];
+            off = B.off[mine];
+            const bool fits = !(o0 > out_cap || feature_count(lw, G) > out_cap - o0);   // never write outside out_idx
+            const bool fast_kind = emit_fast_takes(B, G, lw, off);
+            take = fits && (FAST ? fast_kind : !(fast_ran && fast_kind));
+            if (FAST && fits && !fast_kind) left++;
+        }
+        for (uint64_t todo = __ballot(take); todo; todo &= todo - 1) {
+            const int i = __builtin_ctzll(todo);
+            uint32_t *dst = out_idx + readlane64(o0, i);
+            if constexpr (FAST) {
+                emit_fast(B, G, readlane64(off, i), (uint32_t)__builtin_amdgcn_readlane((int)lw, i), mask,
+                          reinterpret_cast<uint32_t *>(s_wave[wv]), s_tab, lane, dst);
+            } else {
+                uint32_t *hb = reinterpret_cast<uint32_t *>(s_wave[wv] + 2 * SEQB);
+                walk_fragment<HB_EMIT>(B, G, q0 + (uint64_t)i, mask, false, 0u, s_wave[wv], hb, s_tab, lane, [&](uint32_t cnt) {
+                    if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {   // wave-uniform: 16-byte stores, then the tail
+                        const uint32_t n4 = cnt / 4u;
+                        for (uint32_t j = lane; j < n4; j += WAVE)
+                            reinterpret_cast<uint4 *>(dst)[j] = reinterpret_cast<const uint4 *>(hb)[j];
+                        for (uint32_t j = n4 * 4u + lane; j < cnt; j += WAVE) dst[j] = hb[j];
+                    } else {
+                        for (uint32_t j = lane; j < cnt; j += WAVE) dst[j] = hb[j];
+                    }
+                    dst += cnt;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                });
+            }
+        }
+    }
+    if (FAST && left) atomicAdd(queue + 2, left);
 }
 
 // Debug: the t gathered characters of every feature (reference order), t bytes per feature.
@@ -428,7 +807,8 @@ extern "C" int opal_ctx_destroy(opal_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_pos) (void)hipFree(ctx->d_pos);
-    if (ctx->d_w) (void)hipFree(ctx->d_w);
+    if (ctx->d_fast) (void)hipFree(ctx->d_fast);
+    if (ctx->d_w && ctx->w_owned) (void)hipFree(ctx->d_w);
     if (ctx->d_g2) (void)hipFree(ctx->d_g2);
     if (ctx->ing_tiles) (void)hipFree(ctx->ing_tiles);
     if (ctx->ing_rec) (void)hipFree(ctx->ing_rec);
@@ -466,6 +846,38 @@ extern "C" int opal_set_patterns(opal_ctx *ctx, const int32_t *pos, int P, int t
     if (ctx->d_pos) { OPAL_HIP_CHECK(ctx, hipFree(ctx->d_pos)); ctx->d_pos = nullptr; }
     OPAL_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_pos, h.size()));
     OPAL_HIP_CHECK(ctx, hipMemcpy(ctx->d_pos, h.data(), h.size(), hipMemcpyHostToDevice));
+    // emit fast path (see emit_fast): t == 16 and, inside every block of 4, position j at least j (true for ascending rows)
+    if (ctx->d_fast) { OPAL_HIP_CHECK(ctx, hipFree(ctx->d_fast)); ctx->d_fast = nullptr; }
+    bool fast_ok = t == 16, canon2 = false;
+    std::vector<uint32_t> fp((size_t)P * FASTPAT_DW, 0u);
+    auto host_mm_k = [](uint32_t k1) { k1 *= 0xcc9e2d51u; k1 = (k1 << 15) | (k1 >> 17); return k1 * 0x1b873593u; };
+    for (int p = 0; p < P && fast_ok; p++) {
+        uint32_t *r = &fp[(size_t)p * FASTPAT_DW];
+        uint32_t runs = 0;
+        for (int b = 0; b < 4; b++) {
+            bool run = true;
+            for (int j = 0; j < 4; j++) {
+                const int q = pos[p * t + 4 * b + j] - j;
+                if (q < 0) { fast_ok = false; break; }
+                r[4 * b + j] = (uint32_t)(4 * q);
+                run = run && pos[p * t + 4 * b + j] == pos[p * t + 4 * b] + j;
+            }
+            if (run && b > 0 && pos[p * t + 4 * b] != pos[p * t + 4 * b - 4] + 4) run = false;   // blocks must also follow each other
+            if (run) runs |= 1u << b;
+        }
+        if (runs != 0xfu) runs = 0;     // the kernel only distinguishes "one run of 16" from "gather everything"
+        if (p == 0) canon2 = runs == 0xfu;
+        else canon2 = canon2 && runs == 0;
+        const uint32_t digits = p < 10 ? (uint32_t)('0' + p) : ((uint32_t)('0' + p / 10) | ((uint32_t)('0' + p % 10) << 8));
+        r[16] = host_mm_k(digits) ^ (uint32_t)(t + (p < 10 ? 1 : 2));
+        r[17] = runs;
+        r[18] = (uint32_t)(4 * (pos[p * t] + 1));
+    }
+    if (fast_ok) {
+        OPAL_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_fast, fp.size() * sizeof(uint32_t)));
+        OPAL_HIP_CHECK(ctx, hipMemcpy(ctx->d_fast, fp.data(), fp.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    ctx->fast_canon2 = fast_ok && P == 2 && canon2;
     ctx->P = P; ctx->t = t; ctx->k = k;
     ctx->p0_run = pos[0];   // pattern 0 as a run of consecutive positions (Opal's first row: ldpc.py:83-85), else -1
     for (int j = 1; j < t; j++)
@@ -482,6 +894,7 @@ static int alloc_table(opal_ctx *ctx, uint64_t n_slots, int K, int bits)
     const uint64_t need = n_slots + pad;
     OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     OPAL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    opal::drop_adopted_table(ctx);
     if (ctx->w_alloc_floats < need) {
         if (ctx->d_w) { OPAL_HIP_CHECK(ctx, hipFree(ctx->d_w)); ctx->d_w = nullptr; ctx->w_alloc_floats = 0; }
         hipError_t e = hipMalloc((void **)&ctx->d_w, need * sizeof(float));
@@ -519,6 +932,34 @@ extern "C" int opal_set_weights_device(opal_ctx *ctx, const float *d_w, uint64_t
     if (rc) return rc;
     OPAL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_w, d_w, n_slots * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     return finish_table(ctx);
+}
+
+extern "C" int opal_adopt_weights_device(opal_ctx *ctx, float *d_w, uint64_t n_slots, uint64_t capacity_floats, int K, int bits)
+{
+    if (!ctx) return opal::fail(nullptr, OPAL_EINVAL, "opal_adopt_weights_device: null ctx");
+    if (!d_w) return opal::fail(ctx, OPAL_EINVAL, "opal_adopt_weights_device: null table");
+    if (bits < 1 || bits > 32 || n_slots != (1ull << bits))
+        return opal::fail(ctx, OPAL_EINVAL, "opal_adopt_weights_device: need 1 <= bits <= 32 and n_slots == 2^bits");
+    if (K < 1 || K > (1 << 20)) return opal::fail(ctx, OPAL_EINVAL, "opal_adopt_weights_device: need 1 <= K <= 2^20");
+    if (capacity_floats < n_slots + (uint64_t)K + 4)
+        return opal::fail(ctx, OPAL_EINVAL, "opal_adopt_weights_device: the buffer needs room for n_slots + K + 4 floats (the mirror of the table's head)");
+    if ((reinterpret_cast<uintptr_t>(d_w) & 15u) != 0) return opal::fail(ctx, OPAL_EINVAL, "opal_adopt_weights_device: the table must be 16-byte aligned");
+    OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    OPAL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_w && ctx->w_owned) OPAL_HIP_CHECK(ctx, hipFree(ctx->d_w));
+    ctx->d_w = d_w; ctx->w_alloc_floats = capacity_floats; ctx->w_owned = false;
+    ctx->n_slots = n_slots; ctx->K = K; ctx->bits = bits; ctx->g2_valid = false;
+    return finish_table(ctx);
+}
+
+extern "C" int opal_set_tuning(opal_ctx *ctx, int predict_nt, uint64_t emit_qchunk, int emit_fast)
+{
+    if (!ctx) return opal::fail(nullptr, OPAL_EINVAL, "opal_set_tuning: null ctx");
+    if (predict_nt < -1 || predict_nt > 1) return opal::fail(ctx, OPAL_EINVAL, "opal_set_tuning: predict_nt is -1 (by table size), 0 or 1");
+    ctx->tune_nt = predict_nt;
+    ctx->tune_qchunk = emit_qchunk;
+    ctx->tune_emit_fast = emit_fast != 0;
+    return OPAL_OK;
 }
 
 extern "C" int opal_set_vw_options(opal_ctx *ctx, int hash_all, int add_constant, int clip, float min_label, float max_label)
@@ -622,13 +1063,34 @@ extern "C" int opal_features(opal_ctx *ctx, const uint8_t *d_reads, uint64_t rea
     Batch B{d_reads, reads_bytes, d_frag_off, d_frag_len, n};
     Geom G{ctx->d_pos, ctx->k, ctx->P, ctx->t, (ctx->t + 3) & ~3, reverse != 0, ctx->hash_all, ctx->p0_run};
     const uint32_t mask = bits == 32 ? 0xffffffffu : ((1u << bits) - 1u);
+    const uint64_t qchunk = std::min<uint64_t>(ctx->tune_qchunk ? ctx->tune_qchunk : EMIT_QCHUNK, WAVE);
+    // queue words: [0] the fast kernel's work counter, [1] the generic kernel's, [2] fragments the fast kernel left over
+    OPAL_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_queue, 0, 3 * sizeof(unsigned long long), ctx->stream));
+    // the fast kernel reads the batch as dwords: it needs a 4-byte aligned buffer of at least two of them
+    const int fast = ctx->d_fast && ctx->tune_emit_fast && (reinterpret_cast<uintptr_t>(d_reads) & 3u) == 0 && reads_bytes >= 8;
     int grid = 1;
-    rc = grid_for(ctx, (const void *)&emit_idx_kernel, n, &grid);
+    if (fast) {
+        G.fast = ctx->d_fast;
+        G.fast_canon2 = ctx->fast_canon2;
+        // P == 2 makes every fragment's feature count even: with an 8-byte aligned d_out_idx every fragment's range is too
+        if (ctx->fast_canon2 && (reinterpret_cast<uintptr_t>(d_out_idx) & 7u) == 0) {
+            rc = grid_for(ctx, (const void *)&emit_canon2_kernel, n, &grid);
+            if (rc) return rc;
+            hipLaunchKernelGGL(emit_canon2_kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, B, G, mask, d_out_off, d_out_idx, out_cap,
+                               ctx->d_queue, qchunk);
+        } else {
+            rc = grid_for(ctx, (const void *)&emit_idx_kernel<true>, n, &grid);
+            if (rc) return rc;
+            hipLaunchKernelGGL(emit_idx_kernel<true>, dim3(grid), dim3(BLOCK), 0, ctx->stream, B, G, mask, d_out_off, d_out_idx, out_cap,
+                               ctx->d_queue, qchunk, 1);
+        }
+        OPAL_HIP_CHECK(ctx, hipGetLastError());
+    }
+    // every fragment the fast kernel does not take (text, long reads, other geometries); returns at once when there is none
+    rc = grid_for(ctx, (const void *)&emit_idx_kernel<false>, n, &grid);
     if (rc) return rc;
-    OPAL_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), ctx->stream));
-    uint64_t qchunk = EMIT_QCHUNK;
-    if (const char *e = getenv("OPAL_EMIT_QCHUNK")) qchunk = std::max<uint64_t>(1, strtoull(e, nullptr, 10));   // experiments
-    hipLaunchKernelGGL(emit_idx_kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, B, G, mask, d_out_off, d_out_idx, out_cap, ctx->d_queue, qchunk);
+    hipLaunchKernelGGL(emit_idx_kernel<false>, dim3(grid), dim3(BLOCK), 0, ctx->stream, B, G, mask, d_out_off, d_out_idx, out_cap,
+                       ctx->d_queue, qchunk, fast);
     OPAL_HIP_CHECK(ctx, hipGetLastError());
     return OPAL_OK;
 }
@@ -672,9 +1134,8 @@ extern "C" int opal_predict(opal_ctx *ctx, const uint8_t *d_reads, uint64_t read
     const uint32_t mask = ctx->bits == 32 ? 0xffffffffu : ((1u << ctx->bits) - 1u);
     const uint32_t const_idx = OPAL_VW_CONSTANT & mask;
     const Variant &v = pick_variant(ctx->K);
-    // cache policy of the row loads by table size (see nt_load); OPAL_PREDICT_NT=0/1 overrides it for experiments
-    bool nt = ctx->n_slots * sizeof(float) >= NT_TABLE_BYTES;
-    if (const char *e = getenv("OPAL_PREDICT_NT")) nt = atoi(e) != 0;
+    // cache policy of the row loads by table size (see nt_load) unless opal_set_tuning forces one
+    const bool nt = ctx->tune_nt < 0 ? ctx->n_slots * sizeof(float) >= NT_TABLE_BYTES : ctx->tune_nt != 0;
     const void *fn = nt ? v.fn_nt : v.fn;
     int grid = 1;
     rc = grid_for(ctx, fn, n, &grid);

@@ -398,6 +398,7 @@ extern "C" int opal_train_begin(opal_ctx *ctx, int K, int bits, int resume)
     const uint64_t need = n_slots + (uint64_t)K + 4;
     const bool keep = resume && ctx->d_w && ctx->K == K && ctx->bits == bits;
     if (resume && !keep) return opal::fail(ctx, OPAL_ESTATE, "opal_train_begin: resume needs weights with the same K and bits loaded");
+    if (!keep) opal::drop_adopted_table(ctx);   // an adopted table is trained in place when resuming, otherwise left alone
     int rc = alloc_floats(ctx, &ctx->d_w, &ctx->w_alloc_floats, need);
     if (rc) return rc;
     rc = alloc_floats(ctx, &ctx->d_g2, &ctx->g2_alloc_floats, n_slots);
@@ -437,7 +438,9 @@ extern "C" int opal_train_batch(opal_ctx *ctx, const uint8_t *d_reads, uint64_t 
     float *w = ctx->d_w, *g2 = ctx->d_g2;
     int K = ctx->K;
     int phases = 3;
-    if (const char *e = getenv("OPAL_TRAIN_PHASES")) phases = atoi(e);   // profiling experiments only
+#ifdef OPAL_EXPERIMENTS   // profiling builds only: the shipped library reads no environment variable
+    if (const char *e = getenv("OPAL_TRAIN_PHASES")) phases = atoi(e);
+#endif
     TrainArgs ta{eta, l1, l2, ctx->min_label, ctx->max_label, sequential != 0, phases};
     OPAL_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), ctx->stream));
     void *args[] = {&B, &G, &w, &g2, (void *)&mask, &K, (void *)&const_idx, &d_labels, &ta, &d_out_pred, &ctx->d_queue};
@@ -468,6 +471,7 @@ extern "C" int opal_load_weights_sparse(opal_ctx *ctx, const uint32_t *idx, cons
     OPAL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const uint64_t n_slots = 1ull << bits;
     const uint64_t need = n_slots + (uint64_t)K + 4;
+    opal::drop_adopted_table(ctx);
     int rc = alloc_floats(ctx, &ctx->d_w, &ctx->w_alloc_floats, need);
     if (rc) return rc;
     ctx->n_slots = n_slots; ctx->K = K; ctx->bits = bits; ctx->g2_valid = false;

@@ -228,6 +228,18 @@ class Engine:
             check(lib().opal_set_weights_device(self._h, w.data_ptr(), n_slots, K, bits), self._h)
         self.K, self.bits = K, bits
 
+    def adopt_weights(self, w, K: int, bits: int):
+        """w: torch cuda float32 tensor with at least 2^bits + K + 4 elements whose first 2^bits are the table; it is scored
+        in place (no second copy; the tail receives the mirror of the head) and must outlive its use."""
+        n_slots = 1 << bits
+        assert w.is_cuda and w.dtype == self.torch.float32 and w.is_contiguous() and w.numel() >= n_slots + K + 4
+        check(lib().opal_adopt_weights_device(self._h, w.data_ptr(), n_slots, w.numel(), K, bits), self._h)
+        self._adopted = w                      # keeps the tensor alive
+        self.K, self.bits = K, bits
+
+    def set_tuning(self, predict_nt=-1, emit_qchunk=0, emit_fast=True):
+        check(lib().opal_set_tuning(self._h, int(predict_nt), int(emit_qchunk), int(emit_fast)), self._h)
+
     def set_vw_options(self, hash_all=False, add_constant=True, clip=True, min_label=-1.0, max_label=1.0):
         check(lib().opal_set_vw_options(self._h, int(hash_all), int(add_constant), int(clip), min_label, max_label), self._h)
 

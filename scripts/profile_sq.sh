@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/sq_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 300 rocprofv3 --pmc ${OPAL_PMC:-SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE} --output-format csv -d $OUT/sq -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline "$@" > $OUT/sq.log 2>&1 || { echo "SQ pass failed"; tail -5 $OUT/sq.log; exit 1; }
+timeout -s KILL 300 rocprofv3 --pmc ${OPAL_PMC:-SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE} --output-format csv -d $OUT/sq -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-extra "$@" > $OUT/sq.log 2>&1 || { echo "SQ pass failed"; tail -5 $OUT/sq.log; exit 1; }
 python3 - $OUT <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]

@@ -120,9 +120,9 @@ def test_predict_matches_oracle(amd, eng, oracle, golden_dir, K, bits):
 
 
 @pytest.mark.parametrize("K", [1, 3, 10, 64, 130, 356, 1563, 1564, 2050])
-def test_streaming_load_variants_match_oracle(amd, eng, oracle, golden_dir, K, monkeypatch):
+def test_streaming_load_variants_match_oracle(amd, eng, oracle, golden_dir, K):
     """Tables of 4 GiB and more are scored by the kernel variants with non-temporal row loads; here they are forced
-    onto a small table (OPAL_PREDICT_NT=1) so that every (VEC, NV) variant is compared with the oracle bit for bit."""
+    onto a small table (opal_set_tuning) so that every (VEC, NV) variant is compared with the oracle bit for bit."""
     rng = np.random.default_rng(K)
     bits = 18
     pos = _patterns(amd, golden_dir, "patterns_k64_t16_m1_s7.txt", 64)
@@ -133,10 +133,49 @@ def test_streaming_load_variants_match_oracle(amd, eng, oracle, golden_dir, K, m
     eng.set_vw_options()
     batch = eng.upload(amd.PackedReads.from_sequences(seqs))
     ocls, osc, _ = oracle.predict(seqs, 64, pos, True, w, K, bits)
-    for nt in ("1", "0"):
-        monkeypatch.setenv("OPAL_PREDICT_NT", nt)
-        cls, sc = eng.predict(batch, True, want_scores=True)
-        assert np.array_equal(sc.cpu().numpy(), osc) and np.array_equal(cls.cpu().numpy(), ocls), (K, nt)
+    try:
+        for nt in (1, 0):
+            eng.set_tuning(predict_nt=nt)
+            cls, sc = eng.predict(batch, True, want_scores=True)
+            assert np.array_equal(sc.cpu().numpy(), osc) and np.array_equal(cls.cpu().numpy(), ocls), (K, nt)
+    finally:
+        eng.set_tuning()
+
+
+def test_adopted_table_scores_in_place(amd, oracle, golden_dir):
+    """opal_adopt_weights_device: the ctx scores from the caller's padded buffer (no second copy); same scores as the
+    oracle incl. rows that wrap at 2^bits, the caller's table stays as it was, too-small buffers are refused, and a later
+    opal_load_weights / train_begin leaves the caller's buffer alone."""
+    import torch
+    rng = np.random.default_rng(21)
+    K, bits = 356, 12                       # 4096 slots: most rows wrap
+    pos = _patterns(amd, golden_dir, "patterns_k64_t16_m1_s7.txt", 64)
+    e2 = amd.Engine(0)
+    e2.set_patterns(pos, 64)
+    w = (rng.standard_normal(1 << bits) * 0.05).astype(np.float32)
+    buf = torch.full(((1 << bits) + K + 4 + 7,), 123.0, dtype=torch.float32, device=e2.device)
+    buf[:1 << bits] = torch.from_numpy(w).to(e2.device)
+    e2.adopt_weights(buf, K, bits)
+    seqs = _rand_seqs(rng, 40, 200)
+    batch = e2.upload(amd.PackedReads.from_sequences(seqs))
+    cls, sc = e2.predict(batch, True, want_scores=True)
+    ocls, osc, _ = oracle.predict(seqs, 64, pos, True, w, K, bits)
+    assert np.array_equal(sc.cpu().numpy(), osc) and np.array_equal(cls.cpu().numpy(), ocls)
+    assert np.array_equal(buf[:1 << bits].cpu().numpy(), w)
+    assert np.array_equal(buf[1 << bits:(1 << bits) + K + 4].cpu().numpy(), np.resize(w, K + 4))      # the mirror
+    assert float(buf[-1]) == 123.0
+    small = torch.zeros((1 << bits) + K, dtype=torch.float32, device=e2.device)
+    from opal_amd import _lib
+    assert _lib.lib().opal_adopt_weights_device(e2._h, small.data_ptr(), 1 << bits, small.numel(), K, bits) == _lib.OPAL_EINVAL
+    assert b"K + 4" in _lib.lib().opal_last_error(e2._h)
+    e2.load_weights(w * 2, K, bits)                               # the ctx goes back to a table of its own
+    cls2, sc2 = e2.predict(batch, True, want_scores=True)
+    assert np.array_equal(sc2.cpu().numpy(), oracle.predict(seqs, 64, pos, True, w * 2, K, bits)[1])
+    assert np.array_equal(buf[:1 << bits].cpu().numpy(), w)
+    e2.adopt_weights(buf, K, bits)
+    e2.train_begin(K, bits)                                       # a fresh table for the learner, not the caller's
+    assert float(e2.get_weights().abs().max()) == 0.0 and np.array_equal(buf[:1 << bits].cpu().numpy(), w)
+    e2.close()
 
 
 @pytest.mark.parametrize("pattern,k", [("patterns_k64_t16_m4_s7.txt", 64), ("patterns_k64_t16_m8_s7.txt", 64),
@@ -517,6 +556,48 @@ def test_full_size_configs_properties(amd, oracle, golden_dir):
         o3, _, _ = oracle.predict((blob[:ms * L + 1], soff[:ms + 1]), 64, pos, True, wh, K, bits, want_scores=False, nthreads=0)
         assert np.array_equal(c3.cpu().numpy(), o3)
         del c2, s2, sc, cls
+    eng.close()
+
+
+def test_cfg3_per_gpu_share_12p5M_fragments(amd, oracle, golden_dir):
+    """BASELINE.json configs[2] at its real per-GPU size: 12.5 M fragments of 200 bp (100 M over 8 GPUs), K=1564, 2^31-slot
+    table scored in place (opal_adopt_weights_device).  Sharding invariance over three uneven shards (what --gpus N does with
+    contiguous ranges) and the oracle, bit for bit, on samples from the start, the middle and the end of the batch."""
+    import torch
+    from opal_amd.engine import DeviceBatch
+    eng = amd.Engine(0)
+    dev = eng.device
+    n, L, bits, K = 12_500_000, 200, 31, 1564
+    pos = _patterns(amd, golden_dir, "patterns_k64_t16_m1_s7.txt", 64)
+    eng.set_patterns(pos, 64)
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    data = torch.randint(0, 256, (n * 50,), dtype=torch.uint8, device=dev, generator=g)     # 50 random bytes = 200 uniform bases
+    off = torch.arange(n, dtype=torch.int64, device=dev) * L
+    ln = torch.full((n,), L, dtype=torch.int32, device=dev)
+    w = torch.empty((1 << bits) + K + 4, dtype=torch.float32, device=dev)
+    w[:1 << bits].normal_(0.0, 0.05, generator=g)
+    eng.adopt_weights(w, K, bits)
+    eng.set_vw_options()
+
+    def view(lo, hi):
+        return DeviceBatch(data, off[lo:hi], ln[lo:hi], hi - lo, n * 50)
+
+    cls, _ = eng.predict(view(0, n), True)
+    cls = cls.clone()
+    assert int(cls.min()) >= 1 and int(cls.max()) <= K
+    cuts = [0, n // 8 + 3, n // 8 + n // 2, n]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        c, _ = eng.predict(view(lo, hi), True)
+        assert torch.equal(c, cls[lo:hi])
+    wh = w[:1 << bits].cpu().numpy()
+    ms = 400
+    for lo in (0, n // 2 - 7, n - ms):
+        packed = data[lo * 50:(lo + ms) * 50].cpu().numpy().reshape(ms, 50)
+        codes = ((packed[:, :, None] >> (np.arange(4, dtype=np.uint8) * 2)[None, None, :]) & 3).reshape(ms, L)
+        seqs = [ACGT[c].tobytes() for c in codes]
+        ocls, _, _ = oracle.predict(seqs, 64, pos, True, wh, K, bits, want_scores=False, nthreads=0)
+        assert np.array_equal(cls[lo:lo + ms].cpu().numpy(), ocls), lo
     eng.close()
 
 
