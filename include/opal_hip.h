@@ -139,7 +139,10 @@ int opal_fragment_views(opal_ctx *ctx, const uint64_t *d_genome_off, const uint3
  * reference's order (forward strand window-major / pattern-minor, then the reverse complement).
  * d_out_off must have been filled by opal_feature_offsets with the same `reverse`.  out_cap = number of
  * indices d_out_idx can hold (normally d_out_off[n]); a fragment whose range would pass it is not written,
- * so offsets that belong to another batch cannot make the kernel write outside the buffer.                  */
+ * so offsets that belong to another batch cannot make the kernel write outside the buffer.  A fragment whose
+ * (offset, length) reaches outside d_reads has no bases to hash but still owns a range (the offsets come from the
+ * lengths alone): its range is filled with 0xffffffff (NUL bytes in opal_feature_names) and the next opal_sync
+ * returns OPAL_EINVAL saying how many there were.                                                            */
 int opal_features(opal_ctx *ctx, const uint8_t *d_reads, uint64_t reads_bytes, const uint64_t *d_frag_off,
                   const uint32_t *d_frag_len, uint64_t n, int reverse, int bits, const uint64_t *d_out_off,
                   uint32_t *d_out_idx, uint64_t out_cap);

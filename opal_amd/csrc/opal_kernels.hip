@@ -430,6 +430,14 @@ __global__ __launch_bounds__(BLOCK) void emit_idx_kernel(Batch B, Geom G, uint32
                 emit_fast(B, G, readlane64(off, i), (uint32_t)__builtin_amdgcn_readlane((int)lw, i), mask,
                           reinterpret_cast<uint32_t *>(s_wave[wv]), s_tab, lane, dst);
             } else {
+                // a fragment whose (offset, length) reaches outside d_reads has no bases to hash, yet owns a range of the
+                // output (the offsets come from the lengths alone): fill it with 0xffffffff and count it for opal_sync
+                if (locate_fragment(B, q0 + (uint64_t)i).len == 0) {
+                    const uint64_t cnt = feature_count((uint32_t)__builtin_amdgcn_readlane((int)lw, i), G);
+                    for (uint64_t j = lane; j < cnt; j += WAVE) dst[j] = 0xffffffffu;
+                    if (cnt && lane == 0) atomicAdd(queue + 3, 1ull);
+                    continue;
+                }
                 uint32_t *hb = reinterpret_cast<uint32_t *>(s_wave[wv] + 2 * SEQB);
                 walk_fragment<HB_EMIT>(B, G, q0 + (uint64_t)i, mask, false, 0u, s_wave[wv], hb, s_tab, lane, [&](uint32_t cnt) {
                     if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {   // wave-uniform: 16-byte stores, then the tail
@@ -452,7 +460,8 @@ __global__ __launch_bounds__(BLOCK) void emit_idx_kernel(Batch B, Geom G, uint32
 
 // Debug: the t gathered characters of every feature (reference order), t bytes per feature.
 __global__ __launch_bounds__(BLOCK) void emit_names_kernel(Batch B, Geom G, const uint64_t *__restrict__ out_off,
-                                                            uint8_t *__restrict__ out_names, uint64_t out_cap)
+                                                            uint8_t *__restrict__ out_names, uint64_t out_cap,
+                                                            unsigned long long *__restrict__ queue)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_seq[WPB][SEQB];
     const int lane = threadIdx.x & (WAVE - 1);
@@ -464,6 +473,14 @@ __global__ __launch_bounds__(BLOCK) void emit_names_kernel(Batch B, Geom G, cons
         const FragRef fr = locate_fragment(B, frag);
         const bool raw = fr.raw;
         const uint32_t len = fr.len;
+        if (len == 0 && feature_count(B.len[frag], G) > 0) {   // reaches outside d_reads: NUL names, counted for opal_sync
+            const uint64_t o = out_off[frag], cnt = feature_count(B.len[frag], G);
+            if (o <= out_cap && cnt <= out_cap - o) {
+                for (uint64_t j = lane; j < cnt * (uint64_t)t; j += WAVE) out_names[o * (uint64_t)t + j] = 0;
+                if (lane == 0) atomicAdd(queue + 3, 1ull);
+            }
+            continue;
+        }
         if (len < (uint32_t)k) continue;
         const uint8_t *src = fr.src;
         const uint32_t W = len - (uint32_t)k + 1u;
@@ -783,6 +800,7 @@ extern "C" int opal_ctx_create(int device_id, void *stream, opal_ctx **out)
     // switched streams: work enqueued here is then ordered with the caller's copies without extra events.
     ctx->stream = (hipStream_t)stream;
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_queue, 256);
+    if (e == hipSuccess) e = hipMemset(ctx->d_queue, 0, 256);
     if (e != hipSuccess) {
         std::string m = std::string("opal_ctx_create: ") + hipGetErrorString(e);
         delete ctx;
@@ -822,6 +840,14 @@ extern "C" int opal_sync(opal_ctx *ctx)
 {
     if (!ctx) return opal::fail(nullptr, OPAL_EINVAL, "opal_sync: null ctx");
     OPAL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    // fragments of opal_features / opal_feature_names calls that reached outside their d_reads (queue word 3)
+    unsigned long long bad = 0;
+    OPAL_HIP_CHECK(ctx, hipMemcpy(&bad, ctx->d_queue + 3, sizeof(bad), hipMemcpyDeviceToHost));
+    if (bad) {
+        OPAL_HIP_CHECK(ctx, hipMemset(ctx->d_queue + 3, 0, sizeof(bad)));
+        return opal::fail(ctx, OPAL_EINVAL, std::to_string(bad) + " fragment(s) of the emit calls since the last opal_sync reach outside d_reads "
+                                            "(offset + length beyond reads_bytes): their features were written as 0xffffffff / NUL names");
+    }
     return OPAL_OK;
 }
 
@@ -1109,7 +1135,7 @@ extern "C" int opal_feature_names(opal_ctx *ctx, const uint8_t *d_reads, uint64_
     int grid = 1;
     rc = grid_for(ctx, (const void *)&emit_names_kernel, n, &grid);
     if (rc) return rc;
-    hipLaunchKernelGGL(emit_names_kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, B, G, d_out_off, d_out_names, out_cap);
+    hipLaunchKernelGGL(emit_names_kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, B, G, d_out_off, d_out_names, out_cap, ctx->d_queue);
     OPAL_HIP_CHECK(ctx, hipGetLastError());
     return OPAL_OK;
 }

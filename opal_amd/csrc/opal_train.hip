@@ -244,7 +244,7 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
             auto update_one = [&](uint32_t idx) {
                 const uint32_t row = (idx * Ku) & mask;
                 const bool shared_row = (idx == const_idx) && !ta.sequential;
-                if (shared_row && !reg) {
+                if (shared_row) {   // every example touches the constant row: no plain read-modify-write here, or updates get lost
 #pragma unroll
                     for (int j = 0; j < NV; j++) {
                         if (act[j]) {
@@ -252,7 +252,19 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
                             float gv[VEC];
                             vload<VEC>(g2 + slot, gv);
 #pragma unroll
-                            for (int e = 0; e < VEC; e++) atomicAdd(w + slot + e, (gv[e] > 0.0f) ? upd[j][e] * rsq(gv[e]) : 0.0f);
+                            for (int e = 0; e < VEC; e++) {
+                                const float d = (gv[e] > 0.0f) ? upd[j][e] * rsq(gv[e]) : 0.0f;
+                                if (!reg) {
+                                    atomicAdd(w + slot + e, d);
+                                } else {   // decay and soft threshold are not additive: compare-and-swap until this example's step lands
+                                    unsigned int *pw = reinterpret_cast<unsigned int *>(w + slot + e);
+                                    unsigned int seen = *pw, assumed;
+                                    do {
+                                        assumed = seen;
+                                        seen = atomicCAS(pw, assumed, __float_as_uint(finish_w(__uint_as_float(assumed), d)));
+                                    } while (seen != assumed);
+                                }
+                            }
                         }
                     }
                     return;

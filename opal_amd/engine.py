@@ -10,7 +10,7 @@ import numpy as np
 from . import _lib
 from ._lib import check, lib
 
-__all__ = ["PackedReads", "Rng", "Engine", "GenomeSet", "parse_patterns"]
+__all__ = ["PackedReads", "Rng", "Engine", "GenomeSet", "parse_patterns", "check_geometry"]
 
 
 def parse_patterns(lines, kmer):
@@ -28,6 +28,21 @@ def parse_patterns(lines, kmer):
     else:
         rows = [list(range(kmer))]
     return np.ascontiguousarray(np.array(rows, dtype=np.int32))
+
+
+MAX_K, MAX_T, MAX_P = 256, 64, 64       # OPAL_MAX_K / OPAL_MAX_T / OPAL_MAX_P of include/opal_hip.h
+
+
+def check_geometry(kmer, row_weight, n_patterns):
+    """The limits of libopal_hip.so's kernels, checked before anything is written or uploaded (the reference has none:
+    its getters are Python itemgetters).  Raises ValueError with the flag to change."""
+    if kmer > MAX_K:
+        raise ValueError("k-mer length %d is beyond this build's limit of %d (-k/--kmer)" % (kmer, MAX_K))
+    if row_weight > MAX_T:
+        raise ValueError("%d positions per pattern is beyond this build's limit of %d (--row-weight; without a pattern file the "
+                         "whole k-mer is one pattern, so then -k must be <= %d)" % (row_weight, MAX_T, MAX_T))
+    if n_patterns > MAX_P:
+        raise ValueError("%d patterns is beyond this build's limit of %d (--num-hash must be <= %d)" % (n_patterns, MAX_P, MAX_P - 1))
 
 
 class PackedReads:
@@ -213,6 +228,7 @@ class Engine:
     def set_patterns(self, pos: np.ndarray, k: int):
         pos = np.ascontiguousarray(pos, dtype=np.int32)
         P, t = pos.shape
+        check_geometry(k, t, P)
         check(lib().opal_set_patterns(self._h, pos.ctypes.data, P, t, k), self._h)
         self.k, self.P, self.t = k, P, t
 

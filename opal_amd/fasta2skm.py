@@ -13,7 +13,7 @@ import itertools
 import os
 import sys
 
-from .engine import Engine, PackedReads, parse_patterns
+from .engine import Engine, PackedReads, check_geometry, parse_patterns
 from .fasta_functions import fasta_reader
 
 __all__ = ["update_dictionary", "create_pattern_getters", "main_generator", "main_not_commandline", "main",
@@ -89,6 +89,7 @@ def main_generator(args, engine=None):
     else:
         file_contents = None
     pos = create_pattern_getters(file_contents, args.kmer)
+    check_geometry(args.kmer, pos.shape[1], pos.shape[0])
     eng = engine or Engine(0)
     eng.set_patterns(pos, args.kmer)
     with open(args.input, "r", encoding="latin-1") as input_file:

@@ -17,7 +17,8 @@ import numpy as np
 MAGIC = b"OPALHIP1"
 _HDR = struct.Struct("<8sIIIIffQII")
 
-__all__ = ["save_model", "load_model", "read_header", "import_vw_readable_model"]
+__all__ = ["save_model", "load_model", "read_header", "import_vw_readable_model", "export_vw_readable_model",
+           "read_vw_binary_header"]
 
 
 def _count_nonzero(w, chunk=1 << 27):
@@ -83,8 +84,30 @@ def read_header(path):
                 min_label=minl, max_label=maxl, nnz=nnz, dense=bool(dense))
 
 
+def model_kind(path):
+    """'opal' (native container), 'vw-text' (a `--readable_model` dump) or 'vw-binary' (anything else: what `vw -f` writes)."""
+    with open(path, "rb") as f:
+        head = f.read(16)
+    if head[:8] == MAGIC:
+        return "opal"
+    if head[:8].lower() == b"version ":
+        return "vw-text"
+    return "vw-binary"
+
+
 def load_model(path, engine):
-    """Loads the model into the engine's GPU context (weights + VW switches). Returns the header dict."""
+    """Loads the model into the engine's GPU context (weights + VW switches) and returns the header dict.  Dispatches on
+    the file's first bytes: the native container, a VW `--readable_model` text dump (imported, VW-unverified), or a VW
+    binary regressor, whose header is parsed as far as it can be and then refused with what was found."""
+    kind = model_kind(path)
+    if kind == "vw-text":
+        m = import_vw_readable_model(path)
+        engine.load_weights_sparse(m["idx"], m["val"], m["K"], m["bits"])
+        engine.set_vw_options(False, True, True, m["min_label"], m["max_label"])
+        return dict(bits=m["bits"], K=m["K"], hash_all=False, add_constant=True, clip=True, min_label=m["min_label"],
+                    max_label=m["max_label"], nnz=int(m["idx"].size), dense=False)
+    if kind == "vw-binary":
+        read_vw_binary_header(path)        # always raises, with the fields it could parse
     h = read_header(path)
     with open(path, "rb") as f:
         f.seek(_HDR.size)
@@ -140,3 +163,80 @@ def import_vw_readable_model(path):
         raise RuntimeError("%s: not a VW readable model with `bits:` and `--oaa K`" % path)
     return dict(idx=np.array(idx, dtype=np.uint32), val=np.array(val, dtype=np.float32), K=K, bits=bits,
                 min_label=minl, max_label=maxl)
+
+
+def export_vw_readable_model(path, w, K, bits, min_label=-1.0, max_label=1.0, version="8.6.1"):
+    """Writes the compact table as a VW `--readable_model` text dump in the layout import_vw_readable_model reads (so the
+    two round-trip), for the day a real vw is at hand: the harness (tests/test_vw_parity.py) can then diff one of OUR models,
+    slot by slot, against the `--readable_model` dump of a vw trained on the same stream (vw itself loads only binary
+    regressors, so this is the direction text can travel).  VW-unverified like the importer.  Returns the number of lines."""
+    idx, val = _nonzero_chunks(w)
+    with open(path, "w") as f:
+        f.write("Version %s\nId \nMin label:%s\nMax label:%s\nbits:%d\nlda:0\n0 ngram:\n0 skip:\n"
+                "options: --oaa %d\nChecksum: 0\n:0\n" % (version, repr(float(min_label)), repr(float(max_label)), bits, K))
+        for a in range(0, idx.size, 1 << 20):
+            f.write("".join("%d:%s\n" % (i, repr(float(v))) for i, v in zip(idx[a:a + (1 << 20)].tolist(), val[a:a + (1 << 20)].tolist())))
+    return int(idx.size)
+
+
+def read_vw_binary_header(path):
+    """[VW-unverified] Parses the start of a VW 8.x binary regressor (what `vw -f model` at reference opal.py:309 writes)
+    as far as its layout is known from VW's published save_load_header: u32 length + version string; u32 length + id
+    string; the byte 'm'; f32 min_label; f32 max_label; u32 bits; u32 lda; u32 ngram count (+ that many 3-byte strings);
+    u32 skip count (+ strings); u32 length + options string; u32 checksum.  It stops at the first field that is not
+    plausible and ALWAYS raises RuntimeError with the fields read so far: the weight section of a `--save_resume`
+    regressor (per-slot adaptive/normalised state, stride) cannot be verified without a vw binary, so it is never loaded."""
+    fields = {}
+    with open(path, "rb") as f:
+        data = f.read(1 << 16)
+    pos = 0
+
+    def stop(why):
+        got = ", ".join("%s=%r" % kv for kv in fields.items()) or "nothing"
+        raise RuntimeError("%s is not an opal_amd model; as a VW binary regressor its header reads: %s; stopped at offset %d: %s. "
+                           "A VW regressor cannot be loaded (no vw here to pin its weight layout): re-train with opal_amd, or "
+                           "dump it with `vw --readable_model` and load that text file." % (path, got, pos, why))
+
+    def u32():
+        nonlocal pos
+        if pos + 4 > len(data):
+            stop("file ends inside a 32-bit field")
+        v = struct.unpack_from("<I", data, pos)[0]
+        pos += 4
+        return v
+
+    def string(what, limit):
+        nonlocal pos
+        n = u32()
+        if n > limit or pos + n > len(data):
+            stop("%s length %d is not plausible" % (what, n))
+        raw = data[pos:pos + n]
+        pos += n
+        return raw.rstrip(b"\0").decode("latin-1")
+
+    fields["version"] = string("version string", 64)
+    if not fields["version"] or not all(ch.isdigit() or ch == "." for ch in fields["version"]):
+        stop("version string is not of the form 8.x.y")
+    fields["id"] = string("id string", 4096)
+    if pos >= len(data) or data[pos:pos + 1] != b"m":
+        stop("expected the model marker byte 'm'")
+    pos += 1
+    if pos + 8 > len(data):
+        stop("file ends inside min/max label")
+    fields["min_label"], fields["max_label"] = struct.unpack_from("<ff", data, pos)
+    pos += 8
+    if not (np.isfinite(fields["min_label"]) and np.isfinite(fields["max_label"])):
+        stop("min/max label are not finite")
+    fields["bits"] = u32()
+    if not 1 <= fields["bits"] <= 32:
+        stop("bits is outside 1..32")
+    fields["lda"] = u32()
+    for what in ("ngram", "skip"):
+        cnt = u32()
+        if cnt > 256:
+            stop("%s count %d is not plausible" % (what, cnt))
+        fields[what] = [data[pos + 3 * i:pos + 3 * i + 3].rstrip(b"\0").decode("latin-1") for i in range(cnt)]
+        pos += 3 * cnt
+    fields["options"] = string("options string", 1 << 15)
+    fields["checksum"] = u32()
+    stop("header complete; the weight section is not read")

@@ -19,7 +19,7 @@ import numpy as np
 
 from . import drawfrag, fasta2skm, ldpc
 from . import model as model_io
-from .engine import Engine, GenomeSet, Rng, parse_patterns
+from .engine import Engine, GenomeSet, Rng, check_geometry, parse_patterns
 from .shard import gather_in_rank_order
 
 __version__ = "1.0.0"
@@ -258,6 +258,7 @@ def train(ref_dir, model_dir, args, engine=None):
             raise ValueError("Hierarchy middle level [{}] must divide into k-mer length [{}].".format(hierarchical, kmer))
         if hierarchical % row_weight != 0:
             raise ValueError("Row weight[{}] must divide into middle hierarchical structure weight [{}].".format(row_weight, hierarchical))
+    check_geometry(kmer, row_weight, num_hash + 1)        # before patterns.txt or the model directory are written
     print("================================================\nTraining using Opal (MI355X-native learner)\n{:%Y-%m-%d %H:%M:%S}\n".format(starttime))
     print("frag_length = {}\ncoverage:       {}\nreverse-complements: {}\nk-mer length:   {}".format(frag_length, coverage, reverse, kmer))
     if hierarchical > 0:

@@ -692,6 +692,44 @@ def test_emit_never_writes_past_out_cap(amd, eng, oracle, golden_dir):
     assert bool((names[keep * 16:] == 7).all()) and not bool((names[:keep * 16] == 7).any())
 
 
+def test_fragments_outside_the_buffer_are_marked_and_reported(amd, eng, oracle, golden_dir):
+    """A fragment whose (offset, length) reaches outside d_reads owns a range of the output (offsets come from the lengths
+    alone) but has no bases: its features are written as 0xffffffff / NUL names, every other fragment as usual, and the
+    next opal_sync reports how many there were (once)."""
+    import torch
+    from opal_amd._lib import OPAL_EINVAL, check, lib
+    with open(os.path.join(golden_dir, "patterns_k64_t16_m1_s7.txt")) as f:
+        pos = amd.parse_patterns(f.readlines(), 64)
+    eng.set_patterns(pos, 64)
+    rng = np.random.default_rng(12)
+    seqs = _rand_seqs(rng, 30, 200) + [b"acgtn" * 40]
+    b = eng.upload(amd.PackedReads.from_sequences(seqs))
+    off_bad = b.off.clone()
+    off_bad[7] = b.nbytes * 4 - 100          # packed fragment: 200 bases from 100 bases before the end of the buffer
+    off_bad[30] = b.nbytes - 50              # raw fragment: 200 bytes from 50 bytes before the end
+    off = eng.feature_offsets(b, True)
+    total = int(off[-1].item())
+    oidx, ooff = oracle.features_batch(seqs, 64, pos, True, 31)
+    idx = torch.full((total,), 5, dtype=torch.int32, device=eng.device)
+    check(lib().opal_features(eng._h, b.data.data_ptr(), b.nbytes, off_bad.data_ptr(), b.len.data_ptr(), b.n, 1, 31,
+                              off.data_ptr(), idx.data_ptr(), total), eng._h)
+    assert lib().opal_sync(eng._h) == OPAL_EINVAL and b"2 fragment(s)" in lib().opal_last_error(eng._h)
+    assert lib().opal_sync(eng._h) == 0
+    got = _u32(idx)
+    for i in range(31):
+        a, e = int(ooff[i]), int(ooff[i + 1])
+        if i in (7, 30):
+            assert np.all(got[a:e] == 0xffffffff)
+        else:
+            assert np.array_equal(got[a:e], oidx[a:e])
+    names = torch.full((total * 16,), 7, dtype=torch.uint8, device=eng.device)
+    check(lib().opal_feature_names(eng._h, b.data.data_ptr(), b.nbytes, off_bad.data_ptr(), b.len.data_ptr(), b.n, 1,
+                                   off.data_ptr(), names.data_ptr(), total), eng._h)
+    assert lib().opal_sync(eng._h) == OPAL_EINVAL
+    nm = names.cpu().numpy().reshape(total, 16)
+    assert not nm[int(ooff[7]):int(ooff[8])].any() and not nm[int(ooff[30]):int(ooff[31])].any() and nm[:int(ooff[7])].all()
+
+
 def test_randomised_predict_switches_against_oracle(amd, eng, oracle):
     rng = np.random.default_rng(int(os.environ.get("OPAL_FUZZ_SEED", "77001")))
     for trial in range(int(os.environ.get("OPAL_FUZZ_TRIALS", "40"))):

@@ -25,7 +25,10 @@ def _patterns(amd, golden_dir, fname, k):
         return amd.parse_patterns(f.readlines(), k)
 
 
-@pytest.mark.parametrize("K,bits,l1,l2", [(10, 12, 0.0, 0.0), (356, 16, 0.0, 0.0), (7, 14, 1e-4, 1e-3), (1564, 18, 0.0, 0.0)])
+# (1565, 16) and (2100, 17): more classes than one register chunk holds (4 and 2 chunks) on tables small enough that rows of
+# one example overlap across chunks: the rule is chunk-wise there (oracle/opal_oracle.c orc_train restates exactly that)
+@pytest.mark.parametrize("K,bits,l1,l2", [(10, 12, 0.0, 0.0), (356, 16, 0.0, 0.0), (7, 14, 1e-4, 1e-3), (1564, 18, 0.0, 0.0),
+                                          (1565, 16, 0.0, 0.0), (2100, 17, 0.0, 0.0)])
 def test_sequential_training_matches_oracle(amd, oracle, golden_dir, K, bits, l1, l2):
     rng = np.random.default_rng(K + bits)
     pos = _patterns(amd, golden_dir, "patterns_k64_t16_m1_s7.txt", 64)
@@ -54,6 +57,33 @@ def test_sequential_training_matches_oracle(amd, oracle, golden_dir, K, bits, l1
     ocls, osc, _ = oracle.predict(seqs, 64, pos, True, gw, K, bits)
     assert np.array_equal(sc.cpu().numpy(), osc) and np.array_equal(cls.cpu().numpy(), ocls)
     eng.close()
+
+
+def test_concurrent_training_with_regularisation_keeps_the_shared_row(amd, golden_dir):
+    """--lambda1/--lambda2 in the concurrent mode: the constant row, which every example updates, goes through a
+    compare-and-swap loop (decay and soft threshold are not additive), so no example's step on it is lost: with a tiny
+    regularisation its weights end up where the unregularised run's float atomics put them.  (With a plain
+    read-modify-write most concurrent steps on that row vanished.)  The sequential run is there for the signs only: a
+    concurrent run overshoots it on this row, because thousands of examples read the bias before any has moved it."""
+    rng = np.random.default_rng(3)
+    K, bits = 8, 22
+    pos = _patterns(amd, golden_dir, "patterns_k64_t16_m1_s7.txt", 64)
+    seqs = [bytes(rng.choice(ACGT, size=200)) for _ in range(6000)]       # unrelated fragments: only the constant row is shared
+    labels = np.ones(len(seqs), dtype=np.int32)                          # one class always right: its bias must climb
+    out = {}
+    for name, sequential, l1, l2 in (("seq", True, 1e-7, 1e-6), ("conc", False, 0.0, 0.0), ("conc_reg", False, 1e-7, 1e-6)):
+        eng = amd.Engine(0)
+        eng.set_patterns(pos, 64)
+        eng.train_begin(K, bits)
+        batch = eng.upload(amd.PackedReads.from_sequences(seqs))
+        eng.train_batch(batch, labels, True, eta=0.5, l1=l1, l2=l2, sequential=sequential)
+        w = eng.get_weights(to_host=True)
+        crow = (11650396 & ((1 << bits) - 1)) * K & ((1 << bits) - 1)
+        out[name] = w[crow:crow + K].copy()
+        eng.close()
+    for v in out.values():
+        assert v[0] > 0.05 and np.all(v[1:] < -0.05)
+    assert np.allclose(out["conc_reg"], out["conc"], rtol=0.1), (out["conc_reg"], out["conc"])
 
 
 def _make_genomes(rng, n_genomes, glen, divergence):

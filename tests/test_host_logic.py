@@ -220,6 +220,32 @@ def test_model_container_roundtrip_on_cpu(tmp_path):
     bad.write_bytes(b"\x06\x00\x00\x008.6.1\x00m")      # how a VW binary regressor starts
     with pytest.raises(RuntimeError):
         model_io.read_header(str(bad))
+    # load_model dispatches on the first bytes: a VW binary regressor's header is parsed as far as it goes, then refused
+    import struct
+    opts = b" --oaa 7 --random_seed 420\0"
+    vwbin = (struct.pack("<I", 6) + b"8.6.1\0" + struct.pack("<I", 1) + b"\0" + b"m" + struct.pack("<ffII", -1.0, 1.0, 14, 0) +
+             struct.pack("<I", 0) + struct.pack("<I", 0) + struct.pack("<I", len(opts)) + opts + struct.pack("<I", 0xdeadbeef) +
+             b"\x00" * 64)
+    (tmp_path / "vw_final.model").write_bytes(vwbin)
+    assert model_io.model_kind(str(tmp_path / "vw_final.model")) == "vw-binary"
+    with pytest.raises(RuntimeError) as ei:
+        model_io.load_model(str(tmp_path / "vw_final.model"), FakeEngine())
+    msg = str(ei.value)
+    assert "version='8.6.1'" in msg and "bits=14" in msg and "--oaa 7" in msg and "header complete" in msg
+    with pytest.raises(RuntimeError) as ei:
+        model_io.load_model(str(bad), FakeEngine())
+    assert "version='8.6.1'" in str(ei.value) and "id string" in str(ei.value) or "32-bit field" in str(ei.value)
+    # the --readable_model text form round-trips through its own writer, and load_model accepts it
+    txt = str(tmp_path / "readable_final.model")
+    assert model_io.export_vw_readable_model(txt, w, 7, 14, min_label=-2.0, max_label=3.0) == 500
+    assert model_io.model_kind(txt) == "vw-text"
+    m = model_io.import_vw_readable_model(txt)
+    back2 = np.zeros_like(w)
+    back2[m["idx"]] = m["val"]
+    assert np.array_equal(back2, w) and (m["K"], m["bits"], m["min_label"], m["max_label"]) == (7, 14, -2.0, 3.0)
+    e3 = FakeEngine()
+    h3 = model_io.load_model(txt, e3)
+    assert (h3["K"], h3["bits"], h3["nnz"]) == (7, 14, 500) and np.array_equal(np.sort(e3.sparse[0]), np.sort(nz.astype(np.uint32)))
 
 
 def test_cli_parser_matches_reference_defaults():
@@ -246,6 +272,15 @@ def test_cli_parser_matches_reference_defaults():
         opal.train(d, os.path.join(d, "m"), ns)
     with pytest.raises(RuntimeError):                    # reference opal.py:93-96
         opal.get_fasta_and_taxid(tempfile.mkdtemp())
+    # kernel limits are reported before anything is written: --num-hash 64 (65 patterns), a 320-mer
+    for bad in (dict(num_hash=64), dict(kmer=320, row_weight=16)):
+        d2 = tempfile.mkdtemp()
+        open(os.path.join(d2, "a.fasta"), "w").write(">g\nACGT\n")
+        open(os.path.join(d2, "a.taxid"), "w").write("1\n")
+        ns2 = argparse.Namespace(**{**vars(ns), "row_weight": 16, **bad})
+        with pytest.raises(ValueError, match="limit"):
+            opal.train(d2, os.path.join(d2, "m"), ns2)
+        assert not os.path.exists(os.path.join(d2, "m"))
 
 
 def test_opal_helpers_match_reference(golden_dir, tmp_path, capsys):

@@ -74,6 +74,14 @@ __global__ __launch_bounds__(256) void probe(float *__restrict__ a, float *__res
                     f4 t; t.x = va[u].x + 1.f; t.y = va[u].y + 1.f; t.z = va[u].z + 1.f; t.w = va[u].w + 1.f;
                     __builtin_nontemporal_store(t, reinterpret_cast<f4 *>(a + (size_t)row[u] + c));
                 }
+                if (MODE == 8) {   // integer atomic adds without return (deterministic accumulation: order does not matter)
+                    int *ia = reinterpret_cast<int *>(a + (size_t)row[u] + c);
+                    atomicAdd(ia, 1); atomicAdd(ia + 1, 2); atomicAdd(ia + 2, 3); atomicAdd(ia + 3, (int)r0);
+                }
+                if (MODE == 9) {   // float atomic adds without return
+                    float *fa = a + (size_t)row[u] + c;
+                    atomicAdd(fa, 1.f); atomicAdd(fa + 1, 2.f); atomicAdd(fa + 2, 3.f); atomicAdd(fa + 3, 4.f);
+                }
                 if (MODE == 3) { vb[u].x += va[u].x; vb[u].y += va[u].y; vb[u].z += va[u].z; vb[u].w += va[u].w; *reinterpret_cast<float4 *>(b + (size_t)row[u] + c) = vb[u]; }
             }
         }
@@ -101,10 +109,10 @@ static void run(float *a, float *b, float *sink, uint32_t mask, uint32_t K, int 
     float ms = 0;
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double rows = (double)grid * 4 * rows_per_wave;
-    const double units = (MODE == 0 || MODE == 1 || MODE == 5) ? 1 : (MODE == 3 ? 3 : 2);
+    const double units = (MODE == 0 || MODE == 1 || MODE == 5) ? 1 : (MODE == 3 ? 3 : 2);   // atomics: a read and a write at the L2
     const double bytes = rows * K * 4.0 * units;
     printf("mode=%s U=%d waves/CU=%2d K=%u  %.2f ms  %.2f TB/s (%.0f row-units)\n",
-           MODE == 0 ? "read " : MODE == 1 ? "write" : MODE == 2 ? "rmw  " : MODE == 3 ? "r+rmw" : MODE == 4 ? "rmw+p" : MODE == 5 ? "rd nt" : MODE == 6 ? "rmwNN" : "rmw-N", U, blocks_per_cu * 4, K, ms, bytes / ms / 1e9, units);
+           MODE == 0 ? "read " : MODE == 1 ? "write" : MODE == 2 ? "rmw  " : MODE == 3 ? "r+rmw" : MODE == 4 ? "rmw+p" : MODE == 5 ? "rd nt" : MODE == 6 ? "rmwNN" : MODE == 7 ? "rmw-N" : MODE == 8 ? "atomI" : "atomF", U, blocks_per_cu * 4, K, ms, bytes / ms / 1e9, units);
     fflush(stdout);
     CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
 }
@@ -134,6 +142,9 @@ int main(int argc, char **argv)
         run<4, 4>(a, b, sink, mask, K, bpc, cus);
         run<6, 4>(a, b, sink, mask, K, bpc, cus);
         run<7, 4>(a, b, sink, mask, K, bpc, cus);
+        run<8, 1>(a, b, sink, mask, K, bpc, cus);
+        run<8, 4>(a, b, sink, mask, K, bpc, cus);
+        run<9, 4>(a, b, sink, mask, K, bpc, cus);
         run<3, 2>(a, b, sink, mask, K, bpc, cus);
         run<3, 4>(a, b, sink, mask, K, bpc, cus);
         run<3, 8>(a, b, sink, mask, K, bpc, cus);
