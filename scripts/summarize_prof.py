@@ -28,7 +28,7 @@ def main(out):
     for name, r in sorted(stats.items(), key=lambda kv: -float(kv[1]["TotalDurationNs"])):
         print("%-90s calls %5s  avg %12.1f us  total %10.3f ms  %5s%%" % (
             name[:90], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
-    hot = [n for n in stats if "predict_kernel" in n or "emit_idx_kernel" in n or "train_kernel" in n]
+    hot = [n for n in stats if "predict_kernel" in n or "emit_canon2_kernel" in n or "emit_idx_kernel<true>" in n or "train_kernel" in n]
     if hot:
         res["kernel"] = hot[0]
         res["avg_kernel_ms"] = float(stats[hot[0]]["AverageNs"]) / 1e6
@@ -36,7 +36,7 @@ def main(out):
     for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
         vals = []
         for r in rows(os.path.join(out, sub, "**", "*counter_collection.csv")):
-            if r.get("Counter_Name") == ctr and any(k in r["Kernel_Name"] for k in ("predict_kernel", "emit_idx_kernel", "train_kernel")):
+            if r.get("Counter_Name") == ctr and any(k in r["Kernel_Name"] for k in ("predict_kernel", "emit_canon2_kernel", "emit_idx_kernel<true>", "train_kernel")):
                 vals.append(float(r["Counter_Value"]))
         if vals:
             res[ctr + "_KiB_per_launch"] = sum(vals) / len(vals)
