@@ -76,8 +76,9 @@ int opal_adopt_weights_device(opal_ctx *ctx, float *d_w, uint64_t n_slots, uint6
 /* Tuning knobs for tests and experiments (the defaults are the production settings; the library reads no environment
  * variables).  predict_nt: -1 = row-load cache policy by table size (non-temporal from 4 GiB), 0 = default loads,
  * 1 = non-temporal loads.  emit_qchunk: fragments per work-queue draw of opal_features (at most 64), 0 = default (32).
- * emit_fast: 1 = opal_features hashes short 2-bit packed fragments with its fast kernel (default), 0 = generic kernel only. */
-int opal_set_tuning(opal_ctx *ctx, int predict_nt, uint64_t emit_qchunk, int emit_fast);
+ * emit_fast: 1 = opal_features hashes short 2-bit packed fragments with its fast kernel (default), 0 = generic kernel only.
+ * train_group: examples per group of opal_train_batch's deterministic mode, 0 = default (8192).                        */
+int opal_set_tuning(opal_ctx *ctx, int predict_nt, uint64_t emit_qchunk, int emit_fast, uint64_t train_group);
 
 /* VW behaviours that differ between versions, defaults in brackets:
  * hash_all [0]: 0 = `--hash strings` (all-digit names are read as numbers), 1 = `--hash all`;
@@ -174,8 +175,12 @@ int opal_train_begin(opal_ctx *ctx, int K, int bits, int resume);
 
 /* One pass over a batch of labelled fragments, in the order given (the caller shuffles: opal.py:363).
  * d_labels[i] = VW class id (1..K) of fragment i (the "<label> |" prefix of the line, util/fasta2skm.py:82).
- * eta: learning rate (vw -l, default 0.5); l1/l2: opal.py --lambda1/--lambda2.  sequential=1 runs the examples
- * one after the other on a single wave (deterministic, slow: tests); 0 runs them concurrently (Hogwild).
+ * eta: learning rate (vw -l, default 0.5); l1/l2: opal.py --lambda1/--lambda2.  `sequential` selects the schedule:
+ * 0 = all waves concurrently (Hogwild: fastest, results differ slightly from run to run);
+ * 1 = the examples one after the other on a single wave (the sequential rule itself; slow: tests);
+ * 2 = deterministic and concurrent: groups of examples (opal_set_tuning train_group) score against the table as it was
+ *     when their group began, their updates are applied in one defined order by slot-range owners (opal_dtrain.hip):
+ *     two runs give bit-identical tables.  Allocates its buffers on first use; synchronises the stream once per call.
  * d_out_pred (optional): the class predicted for each example BEFORE its update (progressive validation).   */
 int opal_train_batch(opal_ctx *ctx, const uint8_t *d_reads, uint64_t reads_bytes, const uint64_t *d_frag_off,
                      const uint32_t *d_frag_len, const int32_t *d_labels, uint64_t n, int reverse, float eta, float l1,

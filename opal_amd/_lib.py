@@ -29,7 +29,7 @@ PROTOTYPES = {
     "opal_load_weights": (_int, [_vp, _vp, _u64, _int, _int]),
     "opal_set_weights_device": (_int, [_vp, _vp, _u64, _int, _int]),
     "opal_adopt_weights_device": (_int, [_vp, _vp, _u64, _u64, _int, _int]),
-    "opal_set_tuning": (_int, [_vp, _int, _u64, _int]),
+    "opal_set_tuning": (_int, [_vp, _int, _u64, _int, _u64]),
     "opal_set_vw_options": (_int, [_vp, _int, _int, _int, _f32, _f32]),
     "opal_pack_reads": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, _vp, C.POINTER(_u64)]),
     "opal_rng_create": (_int, [_pp]),

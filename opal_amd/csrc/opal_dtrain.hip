@@ -1,0 +1,505 @@
+// Deterministic concurrent mode of the native one-against-all trainer (opal_train_batch with sequential == 2).
+//
+// Why not "the sequential rule, run concurrently": VW's stream (opal.py:363-367) is serial through the constant row,
+// which every example reads and writes, and VW's row layout makes unrelated rows share slots: at K = 356, b = 31 the
+// 549 rows of 16 random examples already overlap somewhere (rows are K slots wide and start anywhere: (549*16)^2 / 2 *
+// 2K / 2^b = 13 overlapping pairs), so groups of slot-disjoint examples do not exist at any useful size.  Atomics are
+// no way out either: integer or float atomic adds on random rows of an 8 GiB table run at 0.2 TB/s on this GPU, 20x
+// below plain read-modify-write (tools/rmw_probe.hip, profiles/r02_rmw_probe), and float adds do not commute bit for bit.
+//
+// The rule here is group-synchronous and owner-computes; every step has ONE defined order, so two runs give identical
+// tables, and oracle/opal_oracle.c (orc_train_groups) restates it on the CPU:
+//   the stream is cut into groups of GS consecutive examples; per group
+//   A  (one wave per example, tables read-only)   p_c = sum_f w[slot(f,c)] in feature order, constant last;
+//      err_c = y_c - clip(p_c);  q_c = 4 err_c^2;  ppu_c = sum_f 1/sqrt(G[slot(f,c)] + q_c);
+//      u_c = the invariant squared-loss step of opal_train.hip from (err_c, ppu_c, s = eta / sqrt(#features))
+//   S  the group's k-mer rows (row start, example), in (example, feature) order, are stably sorted by PARTITION of the
+//      slot space (2^pshift slots each, at least K: a row spills into the next partition at most)
+//   B  one wave per partition, even partitions first, then odd ones (so concurrently worked rows never share a slot):
+//      its rows in sorted order:  G[slot] += q_c;  w[slot] += u_c / sqrt(G[slot])   (+ l2 decay, l1 threshold)
+//   C  the constant row, examples in order:  G += q_c;  w += u_c / sqrt(G)
+// Like the concurrent mode it is this project's own VW-like rule (VW absent: parity unpinned); unlike it, an example
+// sees the table as it was when its group started (the concurrent mode's waves see whatever 5 000 others have written).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "opal_device.h"
+#include "opal_internal.h"
+
+namespace {
+
+template <int VEC>
+__device__ __forceinline__ void vload(const float *p, float (&o)[VEC])
+{
+    if constexpr (VEC == 4) { const float4 v = *reinterpret_cast<const float4 *>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    else if constexpr (VEC == 2) { const float2 v = *reinterpret_cast<const float2 *>(p); o[0] = v.x; o[1] = v.y; }
+    else o[0] = *p;
+}
+template <int VEC>
+__device__ __forceinline__ void vstore(float *p, const float (&o)[VEC])
+{
+    if constexpr (VEC == 4) *reinterpret_cast<float4 *>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    else if constexpr (VEC == 2) *reinterpret_cast<float2 *>(p) = make_float2(o[0], o[1]);
+    else *p = o[0];
+}
+__device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+
+struct DArgs {
+    float eta, l1, l2, min_label, max_label;
+};
+
+// w after one step d (then optional l2 decay and l1 soft threshold, as opal_train.hip's finish_w)
+__device__ __forceinline__ float step_w(float wold, float d, bool reg, float decay, float shrink)
+{
+    float nw = wold + d;
+    if (reg) {
+        nw *= decay;
+        nw = nw > shrink ? nw - shrink : (nw < -shrink ? nw + shrink : 0.0f);
+    }
+    return nw;
+}
+
+// ------------------------------------------------------------------------------------------ phase A
+// One wave per example of the group.  Writes, per example e: upd[e][K], gsq[e][K], sfac[e] = eta / sqrt(#features), the
+// row start of every k-mer feature into keys[] (value = e) at the example's place in the group's (example, feature)
+// order, and the progressive prediction.  Reads w and G, writes neither.
+template <int VEC, int NV, int U>
+__global__ __launch_bounds__(BLOCK) void dtrain_score_kernel(Batch B, Geom G, const float *__restrict__ w, const float *__restrict__ g2,
+                                                              uint32_t mask, int K, uint32_t const_idx,
+                                                              const int32_t *__restrict__ labels, DArgs ta, uint64_t e0, uint32_t gn,
+                                                              const uint64_t *__restrict__ foff, float *__restrict__ upd_out,
+                                                              float *__restrict__ gsq_out, float *__restrict__ sfac,
+                                                              uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                              int32_t *__restrict__ out_pred, unsigned long long *__restrict__ queue)
+{
+    using V = typename VecOf<VEC>::type;
+    constexpr int CH = WAVE * VEC * NV;
+    __shared__ __attribute__((aligned(16))) uint8_t s_seq[WPB][2 * SEQB];
+    __shared__ __attribute__((aligned(16))) uint32_t s_hb[WPB][HB + HB_PAD];
+    __shared__ uint32_t s_tab[KTAB];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wv = threadIdx.x / WAVE;
+    fill_kmer4_table(s_tab);
+    uint32_t *hb = s_hb[wv];
+    const uint32_t Ku = (uint32_t)K;
+    const bool reg_on = (ta.l1 != 0.0f) || (ta.l2 != 0.0f);
+    for (uint64_t e = next_chunk(queue, lane, 1); e < gn; e = next_chunk(queue, lane, 1)) {
+        const uint64_t frag = e0 + e;
+        const uint32_t label = (uint32_t)(labels[frag] - 1);
+        const uint32_t kbase = (uint32_t)(foff[frag] - foff[e0]);
+        const uint32_t nfe = (uint32_t)(foff[frag + 1] - foff[frag]);      // k-mer features (the constant is not a key)
+        float best = 0.0f;
+        uint32_t best_c = 0xffffffffu;
+        for (uint32_t c0 = 0; c0 < Ku; c0 += CH) {
+            uint32_t loff[NV], cls[NV];
+#pragma unroll
+            for (int j = 0; j < NV; j++) {
+                cls[j] = c0 + (uint32_t)(j * WAVE + lane) * VEC;
+                loff[j] = min(cls[j], Ku - VEC);
+            }
+            V acc[NV];
+#pragma unroll
+            for (int j = 0; j < NV; j++) acc[j] = V{};
+            uint32_t nfeat = 0;
+            walk_fragment(B, G, frag, mask, true, const_idx, s_seq[wv], hb, s_tab, lane, [&](uint32_t cnt) {
+                if (lane < HB_PAD) hb[cnt + lane] = const_idx;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (c0 == 0) {   // the rows of this flush: everything but the constant, which is the example's very last entry
+                    for (uint32_t i = lane; i < cnt; i += WAVE) {
+                        const uint32_t at = nfeat + i;
+                        if (at < nfe) { keys[kbase + at] = (hb[i] * Ku) & mask; vals[kbase + at] = (uint32_t)e; }
+                    }
+                }
+                stream_rows<VEC, NV, U, true>(w, hb, cnt, Ku, mask, loff, acc);
+                nfeat += cnt;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            });
+            if (c0 == 0) {
+                // a fragment that reaches outside the buffer hashes to nothing but owns nfe keys: mark them void
+                for (uint32_t at = (nfeat ? nfeat - 1u : 0u) + lane; at < nfe; at += WAVE) { keys[kbase + at] = 0u; vals[kbase + at] = 0xffffffffu; }
+                if (lane == 0) sfac[e] = ta.eta / sqrtf((float)nfeat);
+            }
+            float err[NV][VEC], gsq[NV][VEC], ppu[NV][VEC];
+            bool act[NV];
+#pragma unroll
+            for (int j = 0; j < NV; j++) {
+                bool any = reg_on;
+#pragma unroll
+                for (int x = 0; x < VEC; x++) {
+                    float p = vget<VEC>(acc[j], x);
+                    if (p != p) p = 0.0f;
+                    else if (p > ta.max_label) p = ta.max_label;
+                    else if (p < ta.min_label) p = ta.min_label;
+                    const uint32_t c = cls[j] + x;
+                    if (cls[j] < Ku && (best_c == 0xffffffffu || p > best)) { best = p; best_c = c; }
+                    const float y = (c == label) ? 1.0f : -1.0f;
+                    err[j][x] = y - p;
+                    gsq[j][x] = 4.0f * err[j][x] * err[j][x];
+                    ppu[j][x] = 0.0f;
+                    any = any || (err[j][x] != 0.0f);
+                }
+                act[j] = any && (cls[j] < Ku);
+            }
+            const float s = ta.eta / sqrtf((float)nfeat);
+            // ppu: a read-only sweep over the accumulator rows, 4 rows in flight, loads unconditional (idle lanes read slot 0)
+            walk_fragment(B, G, frag, mask, true, const_idx, s_seq[wv], hb, s_tab, lane, [&](uint32_t cnt) {
+                constexpr int U2 = (NV <= 2) ? 4 : (NV == 4 ? 2 : 1);
+                uint32_t f = 0;
+                for (; f + U2 <= cnt; f += U2) {
+                    float gv[U2][NV][VEC];
+#pragma unroll
+                    for (int u = 0; u < U2; u++) {
+                        const uint32_t row = ((uint32_t)__builtin_amdgcn_readfirstlane((int)hb[f + u]) * Ku) & mask;
+#pragma unroll
+                        for (int j = 0; j < NV; j++) vload<VEC>(g2 + (act[j] ? (size_t)((row + cls[j]) & mask) : (size_t)0), gv[u][j]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U2; u++)
+#pragma unroll
+                        for (int j = 0; j < NV; j++)
+#pragma unroll
+                            for (int x = 0; x < VEC; x++) {
+                                const float t = gv[u][j][x] + gsq[j][x];
+                                ppu[j][x] += (t > 0.0f) ? rsq(t) : 0.0f;
+                            }
+                }
+                for (; f < cnt; f++) {
+                    const uint32_t row = ((uint32_t)__builtin_amdgcn_readfirstlane((int)hb[f]) * Ku) & mask;
+                    float gv[NV][VEC];
+#pragma unroll
+                    for (int j = 0; j < NV; j++) vload<VEC>(g2 + (act[j] ? (size_t)((row + cls[j]) & mask) : (size_t)0), gv[j]);
+#pragma unroll
+                    for (int j = 0; j < NV; j++)
+#pragma unroll
+                        for (int x = 0; x < VEC; x++) {
+                            const float t = gv[j][x] + gsq[j][x];
+                            ppu[j][x] += (t > 0.0f) ? rsq(t) : 0.0f;
+                        }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            });
+#pragma unroll
+            for (int j = 0; j < NV; j++) {
+                float u[VEC], q[VEC];
+#pragma unroll
+                for (int x = 0; x < VEC; x++) {
+                    const float z = s * ppu[j][x];
+                    float v;
+                    if (err[j][x] == 0.0f || ppu[j][x] == 0.0f) v = 0.0f;
+                    else if (z < 1e-6f) v = 2.0f * err[j][x] * s;
+                    else v = err[j][x] * (1.0f - expf(-2.0f * z)) / ppu[j][x];
+                    u[x] = v;
+                    q[x] = gsq[j][x];
+                }
+                if (cls[j] < Ku) {
+                    vstore<VEC>(upd_out + e * (uint64_t)Ku + cls[j], u);
+                    vstore<VEC>(gsq_out + e * (uint64_t)Ku + cls[j], q);
+                }
+            }
+        }
+        if (out_pred) {
+#pragma unroll
+            for (int d = 1; d < WAVE; d <<= 1) {
+                const float ob = __shfl_xor(best, d, WAVE);
+                const uint32_t oc = (uint32_t)__shfl_xor((int)best_c, d, WAVE);
+                const bool take = (oc != 0xffffffffu) && (best_c == 0xffffffffu || ob > best || (ob == best && oc < best_c));
+                if (take) { best = ob; best_c = oc; }
+            }
+            if (lane == 0) out_pred[frag] = (int32_t)(best_c + 1u);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ partition starts
+// pstart[p] = first sorted item of partition p (pstart[NP] = n): every thread looks at one boundary of the sorted keys.
+__global__ void dtrain_starts_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t pshift, uint32_t NP, uint32_t *__restrict__ pstart)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    const uint32_t lo = i == 0 ? 0u : (keys[i - 1] >> pshift) + 1u;       // partitions lo .. hi start at item i
+    const uint32_t hi = i == n ? NP : (keys[i] >> pshift);
+    for (uint32_t p = lo; p <= hi && p <= NP; p++) pstart[p] = i;
+}
+
+// ------------------------------------------------------------------------------------------ phase B
+// One wave per partition of one colour (colour = partition & 1).  Its rows in sorted order, one after the other (the next
+// item's step sizes are fetched while the current row is updated): G += q, w += u / sqrt(G).  Rows of two partitions of one
+// colour never share a slot (a row spills at most into the NEXT partition), so the waves of a launch never meet.
+template <int VEC>
+__global__ __launch_bounds__(BLOCK) void dtrain_apply_kernel(float *__restrict__ w, float *__restrict__ g2, uint32_t mask, int K,
+                                                              const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                              const uint32_t *__restrict__ pstart, uint32_t NP, uint32_t colour,
+                                                              const float *__restrict__ upd, const float *__restrict__ gsq,
+                                                              const float *__restrict__ sfac, DArgs ta, unsigned long long *__restrict__ queue)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const uint32_t Ku = (uint32_t)K;
+    const bool reg = (ta.l1 != 0.0f) || (ta.l2 != 0.0f);
+    const uint32_t nq = (NP - colour + 1u) / 2u;                 // partitions of this colour
+    for (uint64_t q = next_chunk(queue, lane, 1); q < nq; q = next_chunk(queue, lane, 1)) {
+        const uint32_t p = colour + 2u * (uint32_t)q;
+        const uint32_t i0 = pstart[p], i1 = pstart[p + 1];
+        for (uint32_t i = i0; i < i1; i++) {
+            const uint32_t row = (uint32_t)__builtin_amdgcn_readfirstlane((int)keys[i]);
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)vals[i]);
+            if (e == 0xffffffffu) continue;                      // void key (fragment outside its buffer)
+            const float s = sfac[e];
+            const float decay = 1.0f - s * ta.l2, shrink = s * ta.l1;
+            const float *ue = upd + (uint64_t)e * Ku, *qe = gsq + (uint64_t)e * Ku;
+            for (uint32_t c = (uint32_t)lane * VEC; c < Ku; c += WAVE * VEC) {
+                float u[VEC], qv[VEC];
+                vload<VEC>(ue + c, u);
+                vload<VEC>(qe + c, qv);
+                bool any = reg;
+#pragma unroll
+                for (int x = 0; x < VEC; x++) any = any || (qv[x] != 0.0f) || (u[x] != 0.0f);
+                if (!any) continue;                              // classes already at their label: nothing to add (as VW skips zero updates)
+                const size_t slot = (size_t)((row + c) & mask);
+                float gv[VEC], wv[VEC];
+                vload<VEC>(g2 + slot, gv);
+                vload<VEC>(w + slot, wv);
+#pragma unroll
+                for (int x = 0; x < VEC; x++) {
+                    gv[x] += qv[x];
+                    const float d = (gv[x] > 0.0f) ? u[x] * rsq(gv[x]) : 0.0f;
+                    wv[x] = step_w(wv[x], d, reg, decay, shrink);
+                }
+                vstore<VEC>(g2 + slot, gv);
+                vstore<VEC>(w + slot, wv);
+            }
+            // the next row of this partition may be the same row, or overlap it: its loads must see these stores
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ phase C
+// The constant row: one thread per class, the group's examples in order, accumulators in registers.
+__global__ __launch_bounds__(64) void dtrain_const_kernel(float *__restrict__ w, float *__restrict__ g2, uint32_t mask, int K, uint32_t crow,
+                                                           const float *__restrict__ upd, const float *__restrict__ gsq,
+                                                           const float *__restrict__ sfac, uint32_t gn, DArgs ta)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (uint32_t)K) return;
+    const bool reg = (ta.l1 != 0.0f) || (ta.l2 != 0.0f);
+    const size_t slot = (size_t)((crow + c) & mask);
+    float Gc = g2[slot], Wc = w[slot];
+    constexpr uint32_t UN = 8;
+    uint32_t e = 0;
+    for (; e + UN <= gn; e += UN) {
+        float u[UN], q[UN], s[UN];
+#pragma unroll
+        for (uint32_t x = 0; x < UN; x++) { u[x] = upd[(uint64_t)(e + x) * K + c]; q[x] = gsq[(uint64_t)(e + x) * K + c]; s[x] = sfac[e + x]; }
+#pragma unroll
+        for (uint32_t x = 0; x < UN; x++) {
+            if (!reg && q[x] == 0.0f && u[x] == 0.0f) continue;
+            Gc += q[x];
+            const float d = (Gc > 0.0f) ? u[x] * rsq(Gc) : 0.0f;
+            Wc = step_w(Wc, d, reg, 1.0f - s[x] * ta.l2, s[x] * ta.l1);
+        }
+    }
+    for (; e < gn; e++) {
+        const float u = upd[(uint64_t)e * K + c], q = gsq[(uint64_t)e * K + c], s = sfac[e];
+        if (!reg && q == 0.0f && u == 0.0f) continue;
+        Gc += q;
+        const float d = (Gc > 0.0f) ? u * rsq(Gc) : 0.0f;
+        Wc = step_w(Wc, d, reg, 1.0f - s * ta.l2, s * ta.l1);
+    }
+    g2[slot] = Gc;
+    w[slot] = Wc;
+}
+
+__global__ void dtrain_mirror_kernel(float *w, uint64_t n_slots, uint32_t pad)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < pad) w[n_slots + i] = w[i % n_slots];
+}
+
+// strided gather of the group boundaries of the feature offsets: out[g] = foff[min(g * gs, n)]
+__global__ void dtrain_bounds_kernel(const uint64_t *__restrict__ foff, uint64_t n, uint64_t gs, uint64_t ng, uint64_t *__restrict__ out)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g <= ng) out[g] = foff[g * gs < n ? g * gs : n];
+}
+
+struct SVariant {
+    int vec, nv;
+    const void *fn;
+};
+#define OPAL_SV(VEC, NV, U) {VEC, NV, (const void *)&dtrain_score_kernel<VEC, NV, U>}
+const SVariant kScoreVariants[] = {
+    OPAL_SV(1, 1, 8), OPAL_SV(1, 2, 8), OPAL_SV(1, 4, 4), OPAL_SV(1, 8, 2),
+    OPAL_SV(2, 1, 8), OPAL_SV(2, 2, 8), OPAL_SV(2, 4, 4), OPAL_SV(2, 8, 2),
+    OPAL_SV(4, 1, 8), OPAL_SV(4, 2, 8), OPAL_SV(4, 4, 4), OPAL_SV(4, 8, 2),
+};
+
+struct DTrainState {
+    uint64_t *foff = nullptr, *bounds = nullptr;
+    uint64_t foff_cap = 0, bounds_cap = 0;
+    float *upd = nullptr, *gsq = nullptr, *sfac = nullptr;
+    uint64_t upd_cap = 0, gsq_cap = 0, sfac_cap = 0;
+    uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *pstart = nullptr;
+    uint64_t k_cap[2] = {0, 0}, v_cap[2] = {0, 0}, pstart_cap = 0;
+    void *temp = nullptr;
+    size_t temp_cap = 0;
+};
+
+template <class T>
+int grow(opal_ctx *ctx, T **p, uint64_t *cap, uint64_t need)
+{
+    if (*cap >= need) return OPAL_OK;
+    if (*p) { OPAL_HIP_CHECK(ctx, hipFree(*p)); *p = nullptr; *cap = 0; }
+    const hipError_t e = hipMalloc((void **)p, need * sizeof(T));
+    if (e != hipSuccess) return opal::fail(ctx, OPAL_ENOMEM, std::string("deterministic trainer: hipMalloc failed: ") + hipGetErrorString(e));
+    *cap = need;
+    return OPAL_OK;
+}
+
+}  // namespace
+
+void opal::dtrain_free(opal_ctx *ctx)
+{
+    DTrainState *st = static_cast<DTrainState *>(ctx->dtrain);
+    if (!st) return;
+    void *all[] = {st->foff, st->bounds, st->upd, st->gsq, st->sfac, st->keys[0], st->keys[1], st->vals[0], st->vals[1], st->pstart, st->temp};
+    for (void *p : all)
+        if (p) (void)hipFree(p);
+    delete st;
+    ctx->dtrain = nullptr;
+}
+
+// log2 of the partition size: at least K slots (a row may spill into the next partition only), at most 2^14 partitions
+uint32_t opal::dtrain_pshift(int K, int bits)
+{
+    uint32_t ps = 0;
+    while ((1u << ps) < (uint32_t)K) ps++;
+    if (bits > 14 && ps < (uint32_t)bits - 14u) ps = (uint32_t)bits - 14u;
+    return std::min<uint32_t>(ps, (uint32_t)bits);
+}
+
+int opal::train_batch_groups(opal_ctx *ctx, const uint8_t *d_reads, uint64_t reads_bytes, const uint64_t *d_frag_off,
+                             const uint32_t *d_frag_len, const int32_t *d_labels, uint64_t n, int reverse, float eta, float l1, float l2,
+                             int32_t *d_out_pred)
+{
+    if ((uint64_t)ctx->K * 2ull > ctx->n_slots)
+        return opal::fail(ctx, OPAL_EINVAL, "opal_train_batch: the deterministic mode needs a table of at least 2 K slots");
+    if (!ctx->dtrain) ctx->dtrain = new DTrainState;
+    DTrainState *st = static_cast<DTrainState *>(ctx->dtrain);
+    const uint64_t gs = ctx->train_group ? ctx->train_group : 8192;
+    const uint64_t ng = (n + gs - 1) / gs;
+    const int K = ctx->K;
+    int rc = grow(ctx, &st->foff, &st->foff_cap, n + 1);
+    if (rc) return rc;
+    rc = grow(ctx, &st->bounds, &st->bounds_cap, ng + 1);
+    if (rc) return rc;
+    rc = opal_feature_offsets(ctx, d_frag_len, n, reverse, st->foff);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dtrain_bounds_kernel, dim3((unsigned)((ng + 256) / 256)), dim3(256), 0, ctx->stream, st->foff, n, gs, ng, st->bounds);
+    OPAL_HIP_CHECK(ctx, hipGetLastError());
+    std::vector<uint64_t> bounds(ng + 1);
+    OPAL_HIP_CHECK(ctx, hipMemcpyAsync(bounds.data(), st->bounds, (ng + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    OPAL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t max_keys = 1;
+    for (uint64_t g = 0; g < ng; g++) max_keys = std::max(max_keys, bounds[g + 1] - bounds[g]);
+    if (max_keys >= (1ull << 31)) return opal::fail(ctx, OPAL_EINVAL, "opal_train_batch: a group of examples has 2^31 features or more");
+    const uint64_t gmax = std::min<uint64_t>(gs, n);
+    rc = grow(ctx, &st->upd, &st->upd_cap, gmax * (uint64_t)K);
+    if (rc) return rc;
+    rc = grow(ctx, &st->gsq, &st->gsq_cap, gmax * (uint64_t)K);
+    if (rc) return rc;
+    rc = grow(ctx, &st->sfac, &st->sfac_cap, gmax);
+    if (rc) return rc;
+    for (int i = 0; i < 2; i++) {
+        rc = grow(ctx, &st->keys[i], &st->k_cap[i], max_keys);
+        if (rc) return rc;
+        rc = grow(ctx, &st->vals[i], &st->v_cap[i], max_keys);
+        if (rc) return rc;
+    }
+    const uint32_t pshift = opal::dtrain_pshift(K, ctx->bits);
+    const uint32_t NP = (uint32_t)(ctx->n_slots >> pshift);
+    rc = grow(ctx, &st->pstart, &st->pstart_cap, (uint64_t)NP + 2);
+    if (rc) return rc;
+    size_t temp_need = 0;
+    OPAL_HIP_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, temp_need, st->keys[0], st->keys[1], st->vals[0], st->vals[1], (unsigned int)max_keys,
+                                                  pshift, (unsigned int)ctx->bits, ctx->stream));
+    if (st->temp_cap < temp_need) {
+        if (st->temp) { OPAL_HIP_CHECK(ctx, hipFree(st->temp)); st->temp = nullptr; st->temp_cap = 0; }
+        if (hipMalloc(&st->temp, std::max<size_t>(temp_need, 256)) != hipSuccess)
+            return opal::fail(ctx, OPAL_ENOMEM, "deterministic trainer: hipMalloc of the sort's workspace failed");
+        st->temp_cap = std::max<size_t>(temp_need, 256);
+    }
+
+    Batch B{d_reads, reads_bytes, d_frag_off, d_frag_len, n};
+    Geom G{ctx->d_pos, ctx->k, ctx->P, ctx->t, (ctx->t + 3) & ~3, reverse != 0, ctx->hash_all, ctx->p0_run};
+    const uint32_t mask = ctx->bits == 32 ? 0xffffffffu : ((1u << ctx->bits) - 1u);
+    const uint32_t const_idx = OPAL_VW_CONSTANT & mask;
+    const uint32_t crow = (uint32_t)(((uint64_t)const_idx * (uint64_t)K) & mask);
+    const int vec = (K % 4 == 0) ? 4 : (K % 2 == 0) ? 2 : 1;
+    const int need = (K + WAVE * vec - 1) / (WAVE * vec);
+    const int nv = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 8;
+    const void *score_fn = kScoreVariants[0].fn;
+    for (const SVariant &v : kScoreVariants)
+        if (v.vec == vec && v.nv == nv) score_fn = v.fn;
+    const void *apply_fn = vec == 4 ? (const void *)&dtrain_apply_kernel<4> : vec == 2 ? (const void *)&dtrain_apply_kernel<2> : (const void *)&dtrain_apply_kernel<1>;
+    int per_cu_s = 0, per_cu_a = 0;
+    OPAL_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_s, score_fn, BLOCK, 0));
+    OPAL_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_a, apply_fn, BLOCK, 0));
+    per_cu_s = std::max(per_cu_s, 1);
+    per_cu_a = std::max(per_cu_a, 1);
+    DArgs ta{eta, l1, l2, ctx->min_label, ctx->max_label};
+    float *w = ctx->d_w, *g2 = ctx->d_g2;
+    float *upd = st->upd, *gsq = st->gsq, *sfac = st->sfac;
+    const uint64_t *foff = st->foff;
+    unsigned long long *queue = ctx->d_queue;
+
+    for (uint64_t g = 0; g < ng; g++) {
+        uint64_t e0 = g * gs;
+        uint32_t gn = (uint32_t)std::min<uint64_t>(gs, n - e0);
+        const uint32_t nk = (uint32_t)(bounds[g + 1] - bounds[g]);
+        uint32_t *keys_in = st->keys[0], *vals_in = st->vals[0], *keys_s = st->keys[1], *vals_s = st->vals[1];
+        // A: scores, step sizes, row keys (tables read-only)
+        OPAL_HIP_CHECK(ctx, hipMemsetAsync(queue, 0, sizeof(unsigned long long), ctx->stream));
+        {
+            const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((gn + WPB - 1) / WPB, (uint64_t)ctx->num_cus * per_cu_s));
+            void *args[] = {&B, &G, &w, &g2, (void *)&mask, (void *)&K, (void *)&const_idx, &d_labels, &ta, &e0, &gn, &foff, &upd, &gsq, &sfac,
+                            &keys_in, &vals_in, &d_out_pred, &queue};
+            OPAL_HIP_CHECK(ctx, hipLaunchKernel(score_fn, dim3(grid), dim3(BLOCK), args, 0, ctx->stream));
+        }
+        if (nk) {
+            // S: stable sort of the group's rows by partition; where every partition starts
+            size_t tb = st->temp_cap;
+            OPAL_HIP_CHECK(ctx, rocprim::radix_sort_pairs(st->temp, tb, keys_in, keys_s, vals_in, vals_s, nk, pshift, (unsigned int)ctx->bits, ctx->stream));
+            hipLaunchKernelGGL(dtrain_starts_kernel, dim3((nk + 256) / 256), dim3(256), 0, ctx->stream, keys_s, nk, pshift, NP, st->pstart);
+            OPAL_HIP_CHECK(ctx, hipGetLastError());
+            // B: even partitions, then odd ones
+            for (uint32_t colour = 0; colour < 2 && colour < NP; colour++) {
+                const uint32_t nq = (NP - colour + 1u) / 2u;
+                OPAL_HIP_CHECK(ctx, hipMemsetAsync(queue, 0, sizeof(unsigned long long), ctx->stream));
+                const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((nq + WPB - 1) / WPB, (uint64_t)ctx->num_cus * per_cu_a));
+                const uint32_t *ks = keys_s, *vs = vals_s, *ps = st->pstart;
+                const float *cu = upd, *cq = gsq, *cs = sfac;
+                void *args[] = {&w, &g2, (void *)&mask, (void *)&K, &ks, &vs, &ps, (void *)&NP, &colour, &cu, &cq, &cs, &ta, &queue};
+                OPAL_HIP_CHECK(ctx, hipLaunchKernel(apply_fn, dim3(grid), dim3(BLOCK), args, 0, ctx->stream));
+            }
+        }
+        // C: the constant row, examples in order
+        hipLaunchKernelGGL(dtrain_const_kernel, dim3((K + 63) / 64), dim3(64), 0, ctx->stream, w, g2, mask, K, crow, (const float *)upd,
+                           (const float *)gsq, (const float *)sfac, gn, ta);
+        OPAL_HIP_CHECK(ctx, hipGetLastError());
+    }
+    const uint32_t pad = (uint32_t)K + 4;
+    hipLaunchKernelGGL(dtrain_mirror_kernel, dim3((pad + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_w, ctx->n_slots, pad);
+    OPAL_HIP_CHECK(ctx, hipGetLastError());
+    return OPAL_OK;
+}

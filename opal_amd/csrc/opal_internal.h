@@ -31,6 +31,8 @@ struct opal_ctx {
     // tuning (opal_set_tuning): predict row-load policy -1 = by table size, 0 = default loads, 1 = non-temporal; emit draw size 0 = default
     int tune_nt = -1;
     uint64_t tune_qchunk = 0;
+    uint64_t train_group = 0;     // examples per group of the deterministic trainer, 0 = default (8192)
+    void *dtrain = nullptr;       // buffers of the deterministic trainer (opal_dtrain.hip), grown on demand
     bool tune_emit_fast = true;   // false: opal_features uses the generic kernel only (tests compare the two)
     // scratch for the offsets scan
     unsigned long long *d_queue = nullptr;   // work-queue counter of the predict kernel (allocated with the ctx)
@@ -48,6 +50,11 @@ struct opal_ctx {
 
 namespace opal {
 int fail(opal_ctx *ctx, int code, const std::string &msg);
+// the deterministic trainer (opal_dtrain.hip)
+void dtrain_free(opal_ctx *ctx);
+uint32_t dtrain_pshift(int K, int bits);
+int train_batch_groups(opal_ctx *ctx, const uint8_t *d_reads, uint64_t reads_bytes, const uint64_t *d_frag_off, const uint32_t *d_frag_len,
+                       const int32_t *d_labels, uint64_t n, int reverse, float eta, float l1, float l2, int32_t *d_out_pred);
 // forgets a table the ctx does not own, so that the allocation paths below start from "no table"
 inline void drop_adopted_table(opal_ctx *ctx)
 {

@@ -832,6 +832,7 @@ extern "C" int opal_ctx_destroy(opal_ctx *ctx)
     if (ctx->ing_rec) (void)hipFree(ctx->ing_rec);
     if (ctx->d_block_sums) (void)hipFree(ctx->d_block_sums);
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
+    opal::dtrain_free(ctx);
     delete ctx;
     return OPAL_OK;
 }
@@ -978,13 +979,14 @@ extern "C" int opal_adopt_weights_device(opal_ctx *ctx, float *d_w, uint64_t n_s
     return finish_table(ctx);
 }
 
-extern "C" int opal_set_tuning(opal_ctx *ctx, int predict_nt, uint64_t emit_qchunk, int emit_fast)
+extern "C" int opal_set_tuning(opal_ctx *ctx, int predict_nt, uint64_t emit_qchunk, int emit_fast, uint64_t train_group)
 {
     if (!ctx) return opal::fail(nullptr, OPAL_EINVAL, "opal_set_tuning: null ctx");
     if (predict_nt < -1 || predict_nt > 1) return opal::fail(ctx, OPAL_EINVAL, "opal_set_tuning: predict_nt is -1 (by table size), 0 or 1");
     ctx->tune_nt = predict_nt;
     ctx->tune_qchunk = emit_qchunk;
     ctx->tune_emit_fast = emit_fast != 0;
+    ctx->train_group = train_group;
     return OPAL_OK;
 }
 

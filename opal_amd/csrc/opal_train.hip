@@ -435,8 +435,10 @@ extern "C" int opal_train_batch(opal_ctx *ctx, const uint8_t *d_reads, uint64_t 
     if (!ctx->d_w || !ctx->d_g2 || !ctx->g2_valid) return opal::fail(ctx, OPAL_ESTATE, "opal_train_batch: call opal_train_begin first");
     if (n && (!d_reads || !d_frag_off || !d_frag_len || !d_labels)) return opal::fail(ctx, OPAL_EINVAL, "opal_train_batch: null batch pointer");
     if (!(eta > 0.0f) || l1 < 0.0f || l2 < 0.0f) return opal::fail(ctx, OPAL_EINVAL, "opal_train_batch: need eta > 0, l1 >= 0, l2 >= 0");
+    if (sequential < 0 || sequential > 2) return opal::fail(ctx, OPAL_EINVAL, "opal_train_batch: mode is 0 (concurrent), 1 (one wave) or 2 (deterministic groups)");
     if (n == 0) return OPAL_OK;
     OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (sequential == 2) return opal::train_batch_groups(ctx, d_reads, reads_bytes, d_frag_off, d_frag_len, d_labels, n, reverse, eta, l1, l2, d_out_pred);
     Batch B{d_reads, reads_bytes, d_frag_off, d_frag_len, n};
     Geom G{ctx->d_pos, ctx->k, ctx->P, ctx->t, (ctx->t + 3) & ~3, reverse != 0, ctx->hash_all, ctx->p0_run};
     const uint32_t mask = ctx->bits == 32 ? 0xffffffffu : ((1u << ctx->bits) - 1u);

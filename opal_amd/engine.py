@@ -253,8 +253,8 @@ class Engine:
         self._adopted = w                      # keeps the tensor alive
         self.K, self.bits = K, bits
 
-    def set_tuning(self, predict_nt=-1, emit_qchunk=0, emit_fast=True):
-        check(lib().opal_set_tuning(self._h, int(predict_nt), int(emit_qchunk), int(emit_fast)), self._h)
+    def set_tuning(self, predict_nt=-1, emit_qchunk=0, emit_fast=True, train_group=0):
+        check(lib().opal_set_tuning(self._h, int(predict_nt), int(emit_qchunk), int(emit_fast), int(train_group)), self._h)
 
     def set_vw_options(self, hash_all=False, add_constant=True, clip=True, min_label=-1.0, max_label=1.0):
         check(lib().opal_set_vw_options(self._h, int(hash_all), int(add_constant), int(clip), min_label, max_label), self._h)
@@ -319,6 +319,7 @@ class Engine:
 
     def train_batch(self, b: DeviceBatch, labels, reverse: bool, eta=0.5, l1=0.0, l2=0.0, sequential=False, want_pred=False):
         """One pass over the batch in the order given. labels: VW class ids 1..K (numpy int32 or cuda tensor).
+        sequential: False/0 = concurrent (Hogwild), True/1 = one wave, 2 = deterministic groups (include/opal_hip.h).
         Returns the progressive predictions (class predicted before each example's update) or None."""
         t = self.torch
         if isinstance(labels, np.ndarray):

@@ -69,6 +69,10 @@ def lib():
         L.orc_train.argtypes = [C.c_void_p, u64p, C.c_uint64, C.c_int, i32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p, C.c_void_p, C.c_int, C.c_int, i32p, C.c_float, C.c_float, C.c_float,
                                 C.c_float, C.c_float, i32p]
+        L.orc_train_groups.restype = None
+        L.orc_train_groups.argtypes = [C.c_void_p, u64p, C.c_uint64, C.c_int, i32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_int, C.c_int, i32p, C.c_float, C.c_float, C.c_float,
+                                       C.c_float, C.c_float, C.c_uint64, C.c_int, i32p]
         L.orc_rng_new.restype = C.c_void_p
         L.orc_rng_free.argtypes = [C.c_void_p]
         L.orc_rng_seed_limbs.argtypes = [C.c_void_p, u32p, C.c_int]
@@ -208,6 +212,32 @@ def train(seqs, labels, k, pos, reverse, w, g2, K, bits, eta=0.5, l1=0.0, l2=0.0
                 w.ctypes.data, g2.ctypes.data, K, bits, _p(lab, C.c_int32), eta, l1, l2, min_label, max_label,
                 _p(pred, C.c_int32))
     return pred[:n]
+
+
+def train_groups(seqs, labels, k, pos, reverse, w, g2, K, bits, group, pshift, eta=0.5, l1=0.0, l2=0.0, min_label=-1.0,
+                 max_label=1.0, hash_all=False):
+    """CPU statement of the deterministic group-synchronous trainer (opal_dtrain.hip); updates w and g2 in place."""
+    L = lib()
+    blob, off = seqs if isinstance(seqs, tuple) else _concat(seqs)
+    n = len(off) - 1
+    P, t = pos.shape
+    assert w.dtype == np.float32 and g2.dtype == np.float32 and w.size == g2.size == (1 << bits)
+    lab = np.ascontiguousarray(labels, dtype=np.int32)
+    pred = np.zeros(max(n, 1), dtype=np.int32)
+    L.orc_train_groups(blob.ctypes.data, _p(off, C.c_uint64), n, k, _p(pos, C.c_int32), P, t, int(reverse), int(hash_all),
+                       w.ctypes.data, g2.ctypes.data, K, bits, _p(lab, C.c_int32), eta, l1, l2, min_label, max_label,
+                       int(group), int(pshift), _p(pred, C.c_int32))
+    return pred[:n]
+
+
+def train_pshift(K, bits):
+    """log2 of the trainer's partition size (opal::dtrain_pshift): >= K slots, at most 2^14 partitions."""
+    ps = 0
+    while (1 << ps) < K:
+        ps += 1
+    if bits > 14:
+        ps = max(ps, bits - 14)
+    return min(ps, bits)
 
 
 def max_threads():

@@ -59,6 +59,56 @@ def test_sequential_training_matches_oracle(amd, oracle, golden_dir, K, bits, l1
     eng.close()
 
 
+@pytest.mark.parametrize("K,bits,l1,l2,group", [(10, 12, 0.0, 0.0, 7), (356, 16, 0.0, 0.0, 16), (7, 14, 1e-4, 1e-3, 5),
+                                                (1564, 18, 0.0, 0.0, 64), (1565, 16, 0.0, 0.0, 9), (2100, 17, 0.0, 0.0, 30)])
+def test_deterministic_training_matches_oracle_and_itself(amd, oracle, golden_dir, K, bits, l1, l2, group):
+    """opal_train_batch mode 2 (deterministic groups, opal_dtrain.hip): (1) against the CPU statement of the same rule
+    (oracle.train_groups) at 2e-4 (GPU expf / v_rsq_f32 against libm), over several groups, a short last group, repeated
+    and overlapping rows, text fragments, a fragment without k-mers; (2) two GPU runs give bit-identical tables and
+    predictions, although partitions and examples are handed to waves in whatever order the hardware takes them."""
+    rng = np.random.default_rng(K + bits)
+    pos = _patterns(amd, golden_dir, "patterns_k64_t16_m1_s7.txt", 64)
+    seqs = [bytes(rng.choice(ACGT, size=200)) for _ in range(40)]
+    seqs[2] = b"A" * 200                       # every window identical: the same row 137 times in a row
+    seqs[3] = b"ACAC" * 50                     # two alternating rows
+    seqs[4] = seqs[4].lower()                  # raw path
+    seqs[5] = seqs[5][:30]                     # no k-mer: only the constant feature
+    seqs[6] = bytes(rng.choice(ACGT, size=333))
+    seqs += seqs[:9]                           # repeats: weights already touched, the same rows again inside one group
+    labels = rng.integers(1, K + 1, size=len(seqs)).astype(np.int32)
+    pshift = oracle.train_pshift(K, bits)
+    runs = []
+    for rep in range(2):
+        eng = amd.Engine(0)
+        eng.set_patterns(pos, 64)
+        eng.set_tuning(train_group=group)
+        eng.train_begin(K, bits)
+        batch = eng.upload(amd.PackedReads.from_sequences(seqs))
+        w = np.zeros(1 << bits, dtype=np.float32)
+        g2 = np.zeros(1 << bits, dtype=np.float32)
+        got = []
+        for p in range(2):                     # two passes
+            pred = eng.train_batch(batch, labels, True, eta=0.5, l1=l1, l2=l2, sequential=2, want_pred=True)
+            gw = eng.get_weights(to_host=True)
+            got.append((gw, pred.cpu().numpy().copy()))
+            if rep == 0:
+                opred = oracle.train_groups(seqs, labels, 64, pos, True, w, g2, K, bits, group, pshift, eta=0.5, l1=l1, l2=l2)
+                # 2e-4 everywhere but for a handful of slots: the all-A fragment updates ONE row 548 times per pass, scores sit on
+                # the clip boundary there, and expf / v_rsq_f32 against libm decide on which side (seen: 4 slots at 5e-4)
+                off_tol = np.abs(gw - w) > 2e-4 * np.abs(w) + 1e-6
+                assert off_tol.mean() < 1e-3 and np.allclose(gw, w, rtol=2e-3, atol=1e-6), (p, int(off_tol.sum()), np.abs(gw - w).max())
+                assert (got[-1][1] == opred).mean() > 0.9      # ties between near-equal scores may flip
+        runs.append(got)
+        if rep == 0:
+            assert np.count_nonzero(w) > 0
+            cls, sc = eng.predict(batch, True, want_scores=True)          # mirror padding refreshed: usable at once
+            ocls, osc, _ = oracle.predict(seqs, 64, pos, True, gw, K, bits)
+            assert np.array_equal(sc.cpu().numpy(), osc) and np.array_equal(cls.cpu().numpy(), ocls)
+        eng.close()
+    for (wa, pa), (wb, pb) in zip(*runs):
+        assert np.array_equal(wa, wb) and np.array_equal(pa, pb)
+
+
 def test_concurrent_training_with_regularisation_keeps_the_shared_row(amd, golden_dir):
     """--lambda1/--lambda2 in the concurrent mode: the constant row, which every example updates, goes through a
     compare-and-swap loop (decay and soft threshold are not additive), so no example's step on it is lost: with a tiny
