@@ -54,6 +54,13 @@ WORKLOADS = {
     "train_356sp_warm": dict(K=356, n=200_000, pattern="patterns_k64_t16_m1_s7.txt", bits=31, mode="train", cold=False,
                              desc="native OAA learner, later passes over the same 200k fragments: classes already at their "
                                   "label after the clip are skipped, 356 classes, numHash=1, -r, b=31"),
+    "train_356sp_det": dict(K=356, n=200_000, pattern="patterns_k64_t16_m1_s7.txt", bits=31, mode="train", cold=True, tmode=2,
+                            desc="native OAA learner, deterministic mode (groups of 8192 examples, slot-range owners), first pass from a "
+                                 "zeroed table over 200k labelled 200bp fragments, 356 classes, numHash=1, -r, b=31"),
+    "train_356sp_det_warm": dict(K=356, n=200_000, pattern="patterns_k64_t16_m1_s7.txt", bits=31, mode="train", cold=False, tmode=2,
+                                 desc="native OAA learner, deterministic mode, later passes over the same 200k fragments"),
+    "train_1564sp_det": dict(K=1564, n=50_000, pattern="patterns_k64_t16_m1_s7.txt", bits=31, mode="train", cold=True, tmode=2,
+                             desc="native OAA learner, deterministic mode, worst case (zeroed table each step): 50k fragments, 1564 classes"),
     "ingest_reads": dict(K=1, n=4_000_000, pattern="patterns_k64_t16_m1_s7.txt", bits=18, mode="ingest",
                          desc="GPU FASTA ingest (SURVEY.md 8f-3): 4M records of 200 bp as FASTA text resident in HBM -> "
                               "2-bit packed fragment batch (opal_ingest_scan + opal_ingest_fasta)"),
@@ -193,10 +200,13 @@ class Bench:
             eng.train_begin(K, bits)
             if wl.get("cold"):
                 pre_step = lambda: eng.train_begin(K, bits)   # re-zero w and G outside the timed events
-            info.update(kernel="train_kernel", keep=(gs, labels))
+            info.update(kernel="train_kernel" if not wl.get("tmode") else "dtrain_score_kernel + sort + dtrain_apply_kernel x2 + dtrain_const_kernel",
+                        keep=(gs, labels))
+
+            tmode = wl.get("tmode", 0)
 
             def step():
-                eng.train_batch(batch, labels, True, eta=0.5)
+                eng.train_batch(batch, labels, True, eta=0.5, sequential=tmode)
         else:   # ingest: ">%08d\n" + 200 bases + "\n" per record, uniform ACGT (PCG64 seed 1234 + rank)
             rec = np.empty((n, 10 + L + 1), dtype=np.uint8)
             rec[:, 0] = ord(">")

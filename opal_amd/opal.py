@@ -214,6 +214,9 @@ def frag(test_dir, frag_dir, args):
     return 0
 
 
+TRAIN_MODES = {"concurrent": 0, "sequential": 1, "deterministic": 2}      # opal_train_batch's schedule (include/opal_hip.h)
+
+
 # ------------------------------------------------------------------ the training stream (reference opal.py:329-367)
 def batch_label(taxid_line):
     """The label a genome's fragments carry in a training batch: drawfrag writes `<first word of the record name>\t<taxid
@@ -283,8 +286,16 @@ def train(ref_dir, model_dir, args, engine=None):
     eng.set_vw_options()
     eng.train_begin(num_labels, bits)
     final_model_file = model_prefix + "_final.model"
+    # The reference's learner is one vw process fed in order: the same inputs give the same model.  The default schedule
+    # here keeps that property (deterministic groups, opal_dtrain.hip: bit-identical models run to run); `concurrent`
+    # is the Hogwild schedule (as fast or faster on later passes, models differ slightly between runs), `sequential` the
+    # one-wave statement of the rule (slow: for checking).
+    mode_name = getattr(args, "train_mode", None) or os.environ.get("OPAL_TRAIN_MODE", "deterministic")
+    if mode_name not in TRAIN_MODES:
+        raise ValueError("train mode [{}] must be one of {}".format(mode_name, ", ".join(TRAIN_MODES)))
+    train_mode = TRAIN_MODES[mode_name]
     log = open(model_prefix + "_vwps.log", "w")
-    log.write("opal_amd learner: oaa=%d bits=%d l1=%g l2=%g passes=%d\n" % (num_labels, bits, lambda1, lambda2, num_passes))
+    log.write("opal_amd learner: oaa=%d bits=%d l1=%g l2=%g passes=%d schedule=%s\n" % (num_labels, bits, lambda1, lambda2, num_passes, mode_name))
 
     with open(taxids, "r") as f:
         taxid_lines = [l.rstrip("\n") for l in f]
@@ -322,7 +333,7 @@ def train(ref_dir, model_dir, args, engine=None):
         y = np.ascontiguousarray(vwid[keep])
         print("Training on the GPU ...")
         sys.stdout.flush()
-        pred = eng.train_batch(batch, y, reverse, eta=0.5, l1=lambda1, l2=lambda2, want_pred=True)
+        pred = eng.train_batch(batch, y, reverse, eta=0.5, l1=lambda1, l2=lambda2, sequential=train_mode, want_pred=True)
         err = float((pred.cpu().numpy() != y).mean()) if y.size else 0.0
         msg = "batch %d pass 0: %d examples, progressive error %.4f" % (i, y.size, err)
         print(msg)
@@ -345,7 +356,7 @@ def train(ref_dir, model_dir, args, engine=None):
         no_win = 0
         for p in range(1, num_passes):
             for batch, y, _, _ in stream:
-                eng.train_batch(batch, y, reverse, eta=0.5, l1=lambda1, l2=lambda2)
+                eng.train_batch(batch, y, reverse, eta=0.5, l1=lambda1, l2=lambda2, sequential=train_mode)
             e = holdout_error()
             msg = "pass %d: holdout error %.4f" % (p, e)
             print(msg)
@@ -600,6 +611,10 @@ def build_parser():
             p.add_argument(pos_name, help=pos_help)
         if name == "simulate":
             p.add_argument("--do-not-fragment", action="store_true", help="use the test fasta as it is")
+        if name in ("train", "simulate"):
+            p.add_argument("--train-mode", choices=sorted(TRAIN_MODES), default=None,
+                           help="learner schedule (not in the reference, whose vw process is sequential): deterministic = same model "
+                                "every run (default, or $OPAL_TRAIN_MODE); concurrent = Hogwild; sequential = one wave, slow")
         if name == "predict":
             p.add_argument("--dump-vw-text", metavar="FILE", default=None,
                            help="debug: also write the VW text lines the reference would pipe to vw (byte-identical)")

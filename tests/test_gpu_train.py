@@ -234,6 +234,34 @@ def test_cli_simulate_pipeline(amd, tmp_path, capsys):
     assert "micro = %.4f" % micro in capsys.readouterr().out
 
 
+def test_cli_train_is_reproducible_by_default(amd, tmp_path):
+    """The reference's learner is one sequential vw process: the same inputs give the same model.  `opal.py train` keeps that
+    with its default schedule (deterministic groups): two runs write byte-identical vw-model_final.model files and log the
+    schedule; --train-mode concurrent (Hogwild) still trains a usable model."""
+    from opal_amd import opal
+    rng = np.random.default_rng(10)
+    genomes = _make_genomes(rng, 5, 30_000, 0.08)
+    os.makedirs(tmp_path / "train")
+    with open(tmp_path / "train" / "A1.fasta", "w") as f:
+        for i, g in enumerate(genomes):
+            f.write(">g%d\n%s\n" % (i, g.decode()))
+    with open(tmp_path / "train" / "A1.taxid", "w") as f:
+        f.write("".join("%d\n" % (100 + i) for i in range(5)))
+    blobs = []
+    for run in ("a", "b"):
+        np.random.seed(4)                                   # same patterns.txt in both runs (ldpc.py uses numpy's global stream)
+        opal.main(["train", str(tmp_path / "train"), str(tmp_path / run), "-r", "-l", "200", "-c", "3", "--num-hash", "1",
+                   "--num-batches", "2", "--bits", "24"])
+        blobs.append(open(tmp_path / run / "vw-model_final.model", "rb").read())
+        assert "schedule=deterministic" in open(tmp_path / run / "vw-model_vwps.log").readline()
+    assert blobs[0] == blobs[1] and len(blobs[0]) > 10_000
+    np.random.seed(4)
+    opal.main(["train", str(tmp_path / "train"), str(tmp_path / "c"), "-r", "-l", "200", "-c", "3", "--num-hash", "1",
+               "--num-batches", "2", "--bits", "24", "--train-mode", "concurrent"])
+    assert "schedule=concurrent" in open(tmp_path / "c" / "vw-model_vwps.log").readline()
+    assert os.path.getsize(tmp_path / "c" / "vw-model_final.model") > 10_000
+
+
 def test_cli_train_multipass_holdout_and_early_stop(amd, tmp_path):
     """--num-passes > 1 (reference opal.py:316-320: vw --cache_file --passes N on the whole stream): the stream of all
     batches is replayed, every 10th example is held out, the log carries one holdout line per pass and training stops
