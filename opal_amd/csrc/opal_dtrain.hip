@@ -295,7 +295,7 @@ __global__ __launch_bounds__(64) void dtrain_const_kernel(float *__restrict__ w,
     const bool reg = (ta.l1 != 0.0f) || (ta.l2 != 0.0f);
     const size_t slot = (size_t)((crow + c) & mask);
     float Gc = g2[slot], Wc = w[slot];
-    constexpr uint32_t UN = 8;
+    constexpr uint32_t UN = 32;   // loads of 32 examples in flight per thread: the loop is latency-bound (one wave per 64 classes)
     uint32_t e = 0;
     for (; e + UN <= gn; e += UN) {
         float u[UN], q[UN], s[UN];
