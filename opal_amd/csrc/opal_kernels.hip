@@ -292,6 +292,36 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l)
     return ((uint64_t)hi << 32) | lo;
 }
 
+// Work distribution of the emit kernels.  The queue counter is ONE address and same-address atomics retire at ~83 M/s on
+// this GPU (12 ns each): a wave's first draw and its last (the one that tells it the queue is empty) were 2 x 8192 atomics =
+// ~200 us per launch, most of a 200k-fragment batch.  So: wave w owns chunk w outright (no atomic), the counter hands out
+// the chunks after those, and a wave looks at the counter with a plain coherent load first and leaves without an atomic
+// when it is already past the end.
+__device__ __forceinline__ uint64_t emit_first_chunk(int wv, uint64_t qchunk)
+{
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane(wv);   // threadIdx.x / 64 is a VGPR to the compiler: keep the loop scalar
+    return ((uint64_t)blockIdx.x * WPB + (uint64_t)w) * qchunk;
+}
+__device__ __forceinline__ uint64_t emit_next_chunk(unsigned long long *queue, int lane, uint64_t qchunk, uint64_t n)
+{
+    const uint64_t base = (uint64_t)gridDim.x * WPB * qchunk;
+    unsigned long long v = 0;
+    if (base >= n) return n;   // the waves' own chunks cover the batch: nobody touches the counter
+    if (lane == 0) v = atomicAdd(queue, (unsigned long long)qchunk);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return base + (((uint64_t)hi << 32) | lo);
+}
+
+// Adds the fragments a block of the fast kernels left over into queue[2]: per block, not per wave (8192 same-address atomics
+// are 90 us, which is what a launch over an all-text batch cost for taking nothing).
+__device__ __forceinline__ void emit_report_left(uint32_t *s_left, uint32_t left, int lane, unsigned long long *queue)
+{
+    if (left && lane == 0) atomicAdd(s_left, left);
+    __syncthreads();
+    if (threadIdx.x == 0 && *s_left) atomicAdd(queue + 2, (unsigned long long)*s_left);
+}
+
 // ---- The canonical Opal geometry with numHash = 1 (ldpc.py: pattern 0 = a run of 16 positions, pattern 1 = one LDPC row;
 // P = 2, output 8-byte aligned) has a kernel of its own: the two pattern records live in SGPRs for the whole kernel, a step
 // is straight-line code (no pattern loop, no per-pattern dispatch), and the LDS round trips of the two patterns overlap:
@@ -347,6 +377,8 @@ __global__ __launch_bounds__(BLOCK) void emit_canon2_kernel(Batch B, Geom G, uin
     __shared__ uint32_t s_tab[KTAB];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = threadIdx.x / WAVE;
+    __shared__ uint32_t s_left;   // fragments this block leaves to the generic kernel: ONE atomic per block at the end
+    if (threadIdx.x == 0) s_left = 0;
     fill_kmer4_table(s_tab);
     typedef const uint32_t __attribute__((address_space(4))) *const_u32;
     const const_u32 f0 = (const_u32)(uintptr_t)G.fast, f1 = (const_u32)(uintptr_t)(G.fast + FASTPAT_DW);
@@ -357,20 +389,21 @@ __global__ __launch_bounds__(BLOCK) void emit_canon2_kernel(Batch B, Geom G, uin
     uint32_t *zw = s_wave[wv];
     const uint32_t zfa = sgpr((uint32_t)(uintptr_t)zw), zra = zfa + EF_ZLEN * 4u;
     const uint32_t S = G.reverse ? 2u : 1u;
-    unsigned long long left = 0;
-    for (uint64_t q0 = next_chunk(queue, lane, qchunk); q0 < B.n; q0 = next_chunk(queue, lane, qchunk)) {
+    uint32_t left = 0;
+    for (uint64_t q0 = emit_first_chunk(wv, qchunk); q0 < B.n; q0 = emit_next_chunk(queue, lane, qchunk, B.n)) {
         const uint64_t mine = q0 + (uint64_t)lane;
         uint64_t o0 = 0, off = 0;
         uint32_t lw = 0;
-        bool take = false;
+        bool take = false, mine_left = false;
         if ((uint64_t)lane < qchunk && mine < B.n) {
             o0 = out_off[mine];
             lw = B.len[mine];
             off = B.off[mine];
             const bool fits = !(o0 > out_cap || feature_count(lw, G) > out_cap - o0);   // never write outside out_idx
             take = fits && emit_fast_takes(B, G, lw, off);
-            if (fits && !take) left++;
+            mine_left = fits && !take;
         }
+        left += (uint32_t)__popcll(__ballot(mine_left));   // wave-uniform
         for (uint64_t todo = __ballot(take); todo; todo &= todo - 1) {
             const int i = __builtin_ctzll(todo);
             uint32_t *dst = out_idx + readlane64(o0, i);
@@ -388,7 +421,7 @@ __global__ __launch_bounds__(BLOCK) void emit_canon2_kernel(Batch B, Geom G, uin
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
-    if (left) atomicAdd(queue + 2, left);
+    emit_report_left(&s_left, left, lane, queue);
 }
 
 // The two emit kernels share one work loop: a wave draws qchunk (<= 64) consecutive fragments, every lane looks at one of
@@ -396,8 +429,10 @@ __global__ __launch_bounds__(BLOCK) void emit_canon2_kernel(Batch B, Geom G, uin
 // FAST = true: emit_fast for the fragments emit_fast_takes() accepts; counts the others in queue[2].
 // FAST = false: the generic walker for every fragment (fast_ran == 0) or for those the fast kernel left (fast_ran != 0;
 // it returns at once when that kernel left none).
+// amdgpu_waves_per_eu(8, 8): the generic walker fits 64 VGPRs without spilling when told to (left alone the compiler takes 77
+// and loses two waves per SIMD: the text path fell from 327 M to 229 M fragments/s)
 template <bool FAST>
-__global__ __launch_bounds__(BLOCK) void emit_idx_kernel(Batch B, Geom G, uint32_t mask, const uint64_t *__restrict__ out_off,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void emit_idx_kernel(Batch B, Geom G, uint32_t mask, const uint64_t *__restrict__ out_off,
                                                           uint32_t *__restrict__ out_idx, uint64_t out_cap,
                                                           unsigned long long *__restrict__ queue, uint64_t qchunk, int fast_ran)
 {
@@ -407,13 +442,15 @@ __global__ __launch_bounds__(BLOCK) void emit_idx_kernel(Batch B, Geom G, uint32
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = threadIdx.x / WAVE;
     if (!FAST && fast_ran && __builtin_nontemporal_load(queue + 2) == 0ull) return;   // block-uniform: nothing was left over
+    __shared__ uint32_t s_left;
+    if (FAST && threadIdx.x == 0) s_left = 0;
     fill_kmer4_table(s_tab);
-    unsigned long long left = 0;
-    for (uint64_t q0 = next_chunk(queue + (FAST ? 0 : 1), lane, qchunk); q0 < B.n; q0 = next_chunk(queue + (FAST ? 0 : 1), lane, qchunk)) {
+    uint32_t left = 0;
+    for (uint64_t q0 = emit_first_chunk(wv, qchunk); q0 < B.n; q0 = emit_next_chunk(queue + (FAST ? 0 : 1), lane, qchunk, B.n)) {
         const uint64_t mine = q0 + (uint64_t)lane;
         uint64_t o0 = 0, off = 0;
         uint32_t lw = 0;
-        bool take = false;
+        bool take = false, mine_left = false;
         if ((uint64_t)lane < qchunk && mine < B.n) {
             o0 = out_off[mine];
             lw = B.len[mine];
@@ -421,25 +458,31 @@ __global__ __launch_bounds__(BLOCK) void emit_idx_kernel(Batch B, Geom G, uint32
             const bool fits = !(o0 > out_cap || feature_count(lw, G) > out_cap - o0);   // never write outside out_idx
             const bool fast_kind = emit_fast_takes(B, G, lw, off);
             take = fits && (FAST ? fast_kind : !(fast_ran && fast_kind));
-            if (FAST && fits && !fast_kind) left++;
+            mine_left = FAST && fits && !fast_kind;
         }
-        for (uint64_t todo = __ballot(take); todo; todo &= todo - 1) {
-            const int i = __builtin_ctzll(todo);
-            uint32_t *dst = out_idx + readlane64(o0, i);
-            if constexpr (FAST) {
+        if (FAST) left += (uint32_t)__popcll(__ballot(mine_left));   // wave-uniform
+        if constexpr (FAST) {
+            for (uint64_t todo = __ballot(take); todo; todo &= todo - 1) {
+                const int i = __builtin_ctzll(todo);
                 emit_fast(B, G, readlane64(off, i), (uint32_t)__builtin_amdgcn_readlane((int)lw, i), mask,
-                          reinterpret_cast<uint32_t *>(s_wave[wv]), s_tab, lane, dst);
-            } else {
+                          reinterpret_cast<uint32_t *>(s_wave[wv]), s_tab, lane, out_idx + readlane64(o0, i));
+            }
+        } else {
+            // nothing but the mask stays live across the walker (it needs every register it can get: 61 VGPRs, 8 waves per
+            // SIMD; holding the lanes' offsets and lengths for v_readlane cost 15 more and a quarter of the text path's rate)
+            for (uint64_t todo = __ballot(take); todo; todo &= todo - 1) {
+                const uint64_t frag = q0 + (uint64_t)__builtin_ctzll(todo);
+                uint32_t *dst = out_idx + out_off[frag];
                 // a fragment whose (offset, length) reaches outside d_reads has no bases to hash, yet owns a range of the
                 // output (the offsets come from the lengths alone): fill it with 0xffffffff and count it for opal_sync
-                if (locate_fragment(B, q0 + (uint64_t)i).len == 0) {
-                    const uint64_t cnt = feature_count((uint32_t)__builtin_amdgcn_readlane((int)lw, i), G);
+                if (locate_fragment(B, frag).len == 0) {
+                    const uint64_t cnt = feature_count(B.len[frag], G);
                     for (uint64_t j = lane; j < cnt; j += WAVE) dst[j] = 0xffffffffu;
                     if (cnt && lane == 0) atomicAdd(queue + 3, 1ull);
                     continue;
                 }
                 uint32_t *hb = reinterpret_cast<uint32_t *>(s_wave[wv] + 2 * SEQB);
-                walk_fragment<HB_EMIT>(B, G, q0 + (uint64_t)i, mask, false, 0u, s_wave[wv], hb, s_tab, lane, [&](uint32_t cnt) {
+                walk_fragment<HB_EMIT>(B, G, frag, mask, false, 0u, s_wave[wv], hb, s_tab, lane, [&](uint32_t cnt) {
                     if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {   // wave-uniform: 16-byte stores, then the tail
                         const uint32_t n4 = cnt / 4u;
                         for (uint32_t j = lane; j < n4; j += WAVE)
@@ -455,7 +498,7 @@ __global__ __launch_bounds__(BLOCK) void emit_idx_kernel(Batch B, Geom G, uint32
             }
         }
     }
-    if (FAST && left) atomicAdd(queue + 2, left);
+    if constexpr (FAST) emit_report_left(&s_left, left, lane, queue);
 }
 
 // Debug: the t gathered characters of every feature (reference order), t bytes per feature.
@@ -1091,7 +1134,15 @@ extern "C" int opal_features(opal_ctx *ctx, const uint8_t *d_reads, uint64_t rea
     Batch B{d_reads, reads_bytes, d_frag_off, d_frag_len, n};
     Geom G{ctx->d_pos, ctx->k, ctx->P, ctx->t, (ctx->t + 3) & ~3, reverse != 0, ctx->hash_all, ctx->p0_run};
     const uint32_t mask = bits == 32 ? 0xffffffffu : ((1u << bits) - 1u);
-    const uint64_t qchunk = std::min<uint64_t>(ctx->tune_qchunk ? ctx->tune_qchunk : EMIT_QCHUNK, WAVE);
+    // fragments per draw: EMIT_QCHUNK; a batch that the grid's waves cover with one draw each (n <= 32 x #waves, 262k
+    // fragments on a full grid) is dealt out evenly instead, one draw of ceil(n / #waves) per wave and no atomics at all
+    // (with them a 200k-fragment launch cost 16k same-address atomics = 200 us, as much as the work)
+    const uint64_t qmax = std::min<uint64_t>(ctx->tune_qchunk ? ctx->tune_qchunk : EMIT_QCHUNK, WAVE);
+    auto draw_for = [&](int grid_blocks) -> uint64_t {
+        const uint64_t waves = (uint64_t)grid_blocks * WPB;
+        if (ctx->tune_qchunk || n > qmax * waves) return qmax;
+        return (n + waves - 1) / waves;
+    };
     // queue words: [0] the fast kernel's work counter, [1] the generic kernel's, [2] fragments the fast kernel left over
     OPAL_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_queue, 0, 3 * sizeof(unsigned long long), ctx->stream));
     // the fast kernel reads the batch as dwords: it needs a 4-byte aligned buffer of at least two of them
@@ -1105,12 +1156,12 @@ extern "C" int opal_features(opal_ctx *ctx, const uint8_t *d_reads, uint64_t rea
             rc = grid_for(ctx, (const void *)&emit_canon2_kernel, n, &grid);
             if (rc) return rc;
             hipLaunchKernelGGL(emit_canon2_kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, B, G, mask, d_out_off, d_out_idx, out_cap,
-                               ctx->d_queue, qchunk);
+                               ctx->d_queue, draw_for(grid));
         } else {
             rc = grid_for(ctx, (const void *)&emit_idx_kernel<true>, n, &grid);
             if (rc) return rc;
             hipLaunchKernelGGL(emit_idx_kernel<true>, dim3(grid), dim3(BLOCK), 0, ctx->stream, B, G, mask, d_out_off, d_out_idx, out_cap,
-                               ctx->d_queue, qchunk, 1);
+                               ctx->d_queue, draw_for(grid), 1);
         }
         OPAL_HIP_CHECK(ctx, hipGetLastError());
     }
@@ -1118,7 +1169,7 @@ extern "C" int opal_features(opal_ctx *ctx, const uint8_t *d_reads, uint64_t rea
     rc = grid_for(ctx, (const void *)&emit_idx_kernel<false>, n, &grid);
     if (rc) return rc;
     hipLaunchKernelGGL(emit_idx_kernel<false>, dim3(grid), dim3(BLOCK), 0, ctx->stream, B, G, mask, d_out_off, d_out_idx, out_cap,
-                       ctx->d_queue, qchunk, fast);
+                       ctx->d_queue, draw_for(grid), fast);
     OPAL_HIP_CHECK(ctx, hipGetLastError());
     return OPAL_OK;
 }
