@@ -63,7 +63,7 @@ WORKLOADS = {
                              desc="native OAA learner, deterministic mode, worst case (zeroed table each step): 50k fragments, 1564 classes"),
     "ingest_reads": dict(K=1, n=4_000_000, pattern="patterns_k64_t16_m1_s7.txt", bits=18, mode="ingest",
                          desc="GPU FASTA ingest (SURVEY.md 8f-3): 4M records of 200 bp as FASTA text resident in HBM -> "
-                              "2-bit packed fragment batch (opal_ingest_scan + opal_ingest_fasta)"),
+                              "2-bit packed fragment batch (opal_ingest_fasta: one pass over the text)"),
     "train_1564sp": dict(K=1564, n=50_000, pattern="patterns_k64_t16_m1_s7.txt", bits=31, mode="train", cold=True,
                          desc="native OAA learner, worst case (zeroed table each step): 50k labelled 200bp fragments, 1564 classes"),
 }
@@ -224,10 +224,9 @@ class Bench:
             import ctypes as C
             from opal_amd._lib import check, lib
             c_a, c_b = C.c_uint64(), C.c_uint64()
-            info.update(kernel="ing_summary_kernel + ing_scan_kernel + ing_pack_kernel + ing_records_kernel (whole call)")
+            info.update(kernel="ing_fused_kernel + ing_edges_kernel x2 + ing_records_kernel (whole call)")
 
             def step():
-                check(lib().opal_ingest_scan(eng._h, d_text.data_ptr(), nbytes, C.byref(c_a), C.byref(c_b)), eng._h)
                 check(lib().opal_ingest_fasta(eng._h, d_text.data_ptr(), nbytes, ing_reads.data_ptr(), ing_reads.numel(), ing_off.data_ptr(),
                                               ing_len.data_ptr(), n, C.byref(c_a), C.byref(c_b)), eng._h)
                 assert c_a.value == n

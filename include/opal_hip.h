@@ -199,20 +199,22 @@ int opal_load_weights_sparse(opal_ctx *ctx, const uint32_t *idx, const float *va
  * d_text[nbytes] -> fragment batch (d_reads_out, d_frag_off, d_frag_len), one fragment per record in record order.
  * All sequence bytes of the file go into ONE 2-bit stream at the start of d_reads_out; a record made of upper-case
  * ACGT is a view into it (d_frag_off in bases, not byte-aligned), any other record is stored as raw bytes behind the
- * stream (in no particular order).  d_reads_out: 4-byte aligned, reads_cap >= nbytes + nbytes/4 + 64 always suffices
- * (OPAL_ERANGE if it is too small); d_frag_off/d_frag_len: max_records entries (max_records >= number of '>' in the
- * text, or 1).  Record names are not produced.  Synchronises the stream and returns the record count and the bytes
- * of d_reads_out in use through the two host pointers.                                                        */
+ * stream (in no particular order).  d_reads_out: 4-byte aligned, reads_cap >= nbytes + nbytes/4 + 64 always suffices;
+ * d_frag_off/d_frag_len: max_records entries (nbytes/2 + 1 always suffices).  The text is read once (a single-pass
+ * chained scan), so the call needs no sizes in advance: with a buffer that turns out too small it returns OPAL_ERANGE
+ * and reports, through the same two host pointers, the record count and the d_reads_out bytes a second call needs
+ * (bytes = 0, not known yet, when it was max_records that was too small).
+ * Record names are not produced.  Synchronises the stream and returns the record count and the bytes of d_reads_out
+ * in use through the two host pointers.                                                                        */
 int opal_ingest_fasta(opal_ctx *ctx, const uint8_t *d_text, uint64_t nbytes, uint8_t *d_reads_out, uint64_t reads_cap,
                       uint64_t *d_frag_off, uint32_t *d_frag_len, uint64_t max_records, uint64_t *n_records_out,
                       uint64_t *reads_bytes_out);
 
-/* First half of opal_ingest_fasta on its own (two of its three passes): the number of '>' header lines (the record
- * count, or one less when the last record is empty; a text without any header is one record) and of sequence bytes
- * in the text, so that the caller can size d_frag_off / d_frag_len (max_records = max(headers, 1)) and d_reads_out
- * (seq_bytes/4 + 64 if every record is upper-case ACGT, plus the bytes of the records that are not: at most seq_bytes
- * more).  The ctx keeps the result: an opal_ingest_fasta call on the same (d_text, nbytes) that directly follows skips
- * those passes (the text must not change in between).  Synchronises the stream.                                 */
+/* Sizes only: the number of '>' header lines (the record count, or one less when the last record is empty; a text
+ * without any header is one record) and of sequence bytes in the text, for callers that want exact buffers before
+ * opal_ingest_fasta: max_records = max(headers, 1); d_reads_out = seq_bytes/4 + 64 if every record is upper-case ACGT,
+ * plus the bytes of the records that are not (at most seq_bytes more).  One more pass over the text (tile summaries +
+ * a two-level scan); opal_ingest_fasta does not need it.  Synchronises the stream.                               */
 int opal_ingest_scan(opal_ctx *ctx, const uint8_t *d_text, uint64_t nbytes, uint64_t *n_headers_out, uint64_t *seq_bytes_out);
 
 /* Evaluation counts.  Replaces the string compare + groupby of opal.evaluate_predictions (opal.py:111-131):

@@ -11,18 +11,22 @@
 // is summarised as (headers, last event, last line kind, cA, cB, cC): cA = bytes on the line the stretch starts in
 // (sequence iff that line is a data line of an unmuted record), cB = bytes on its own data lines before its first
 // event (sequence iff the record it continues is unmuted), cC = bytes that are sequence whatever came before.
-// Summaries compose associatively, which gives two passes over the text:
-//   1. ing_summary_kernel   one summary per 16 KiB tile (text read once)
-//   2. ing_scan_local_kernel + ing_scan_kernel   two-level scan of the tile summaries (inside segments of 256 tiles, then
-//                           one block over the segment totals) -> the state and sequence position each tile starts at
-//   3. ing_pack_kernel      text read again: every sequence byte now knows its position in the concatenated sequence;
-//                           its 2-bit code goes straight into ONE packed stream of all sequence bytes (LDS-staged,
-//                           whole dwords stored), headers record where their sequence starts, bytes outside ACGT
-//                           flag their record as raw
-//   4. ing_records_kernel   per record: length, offset (packed fragments are addressed in BASES, so a record is a
+// Summaries compose associatively, so the text is read ONCE (opal_ingest_fasta):
+//   1. ing_fused_kernel     a single-pass chained scan.  Persistent blocks take 16 KiB tiles in order; a block analyses its
+//                           tile (the bytes and their masks stay in registers), publishes the tile's summary, looks back
+//                           over its predecessors' published summaries / states until it knows the reader state and the
+//                           sequence position its tile starts at, publishes its own end state, and then packs: the 2-bit
+//                           code of every sequence byte goes straight into ONE packed stream of all sequence bytes
+//                           (LDS-staged, whole dwords stored), headers record where their sequence starts, bytes outside
+//                           ACGT flag their record as raw.  The two dwords a tile may share with its neighbours go to a
+//                           side record instead of HBM;
+//   2. ing_edges_kernel x2  zeroes those shared dwords, then ORs every tile's share in (one thread per tile)
+//   3. ing_records_kernel   per record: length, offset (packed fragments are addressed in BASES, so a record is a
 //                           view into the stream and needs no alignment), space for raw records behind the stream
-//   5. ing_pack_kernel<RAW> only when some record is raw: third pass that copies the bytes of those records
+//   4. ing_rawcopy_kernel   only when some record is raw: second pass that copies the bytes of those records
 // No intermediate copy of the sequence exists; one host synchronisation returns the counts.
+// opal_ingest_scan (sizes only, for callers that want exact buffers first) keeps the two-level scan of tile summaries:
+// ing_summary_kernel + ing_scan_local_kernel + ing_scan_kernel.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -309,8 +313,10 @@ __global__ __launch_bounds__(BLOCK) void ing_scan_local_kernel(const Sum *__rest
 
 // ---- pass 2b: the state every segment starts in (one block over the segment totals) ----------------------------------------------------------------------
 // fin: [0] headers in the text, [1] sequence bytes T, [2] cursor of the raw area (starts behind the packed stream),
-//      [3] raw records, [4] a record is longer than 2^31-1, [5] the last record is empty (dropped), [6] raw area overflow
-enum { F_H = 0, F_T, F_CURSOR, F_NRAW, F_TOOLONG, F_DROPPED, F_OVERFLOW, F_WORDS = 8 };
+//      [3] raw records, [4] a record is longer than 2^31-1, [5] the last record is empty (dropped), [6] raw area overflow,
+//      [7] a byte outside ACGT in front of the first header (makes record 0 raw when the text has no header at all),
+//      [8] a look-back gave up waiting (never seen; the exit every spinning wave reaches)
+enum { F_H = 0, F_T, F_CURSOR, F_NRAW, F_TOOLONG, F_DROPPED, F_OVERFLOW, F_PREBAD, F_STALL, F_WORDS = 16 };
 constexpr int SC_ITEMS = 2;
 constexpr int SC_WAVES = 4;
 constexpr int SC_BLOCK = SC_WAVES * WAVE;
@@ -352,25 +358,7 @@ __global__ __launch_bounds__(SC_BLOCK) void ing_scan_kernel(const Sum *__restric
     }
 }
 
-// The packed stream is stored as whole dwords; only the first and the last dword of a tile can be shared with its
-// neighbours and are OR-ed in atomically, so exactly those must start as zero (zeroing the whole stream instead costs
-// a quarter of the text size in extra HBM writes).
-__global__ __launch_bounds__(BLOCK) void ing_zero_edges_kernel(const Pre *__restrict__ seg_pre, const Sum *__restrict__ tile_excl,
-                                                                uint64_t ntiles, const uint64_t *__restrict__ fin,
-                                                                uint32_t *__restrict__ out32, uint64_t cap_words)
-{
-    const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (t >= ntiles) return;
-    const uint64_t c0 = pre_apply(seg_pre[t / SEG_TILES], tile_excl[t]).cnt;
-    const uint64_t c1 = t + 1 < ntiles ? pre_apply(seg_pre[(t + 1) / SEG_TILES], tile_excl[t + 1]).cnt : fin[F_T];
-    const uint64_t g0 = c0 >> 4;
-    const uint64_t nd = ((c0 & 15u) + (c1 - c0) + 15u) >> 4;      // dwords the tile's pass-3 block will touch
-    if (nd == 0) return;
-    if (g0 < cap_words) out32[g0] = 0u;
-    if (g0 + nd - 1 < cap_words) out32[g0 + nd - 1] = 0u;
-}
-
-// ---- pass 3 (and 5): sequence bytes to their place ------------------------------------------------------------------
+// ---- the single pass: analyse, chain, pack ---------------------------------------------------------------------------
 // removes the 2-bit fields of v whose field in keep (both bits set for a kept field) is clear
 __device__ __forceinline__ uint32_t squeeze_fields(uint32_t v, uint32_t keep)
 {
@@ -387,46 +375,127 @@ __device__ __forceinline__ uint32_t squeeze_fields(uint32_t v, uint32_t keep)
     return v;
 }
 
-// RAWCOPY=false: 2-bit codes of all sequence bytes into the packed stream out32 (base p of the concatenated sequence in
-// bits 2*(p&15) of dword p>>4; the edge dwords of every tile must be zero: tiles meet inside dwords), seq_start[r] for every header,
-// raw_flag[r] for every record that holds a byte outside ACGT.
-// RAWCOPY=true: the bytes of the records flagged raw to out8[frag_off[r] + i].
-template <bool RAWCOPY>
-__global__ __launch_bounds__(BLOCK) void ing_pack_kernel(const uint8_t *__restrict__ text, uint64_t n, const Pre *__restrict__ seg_pre,
-                                                          const Sum *__restrict__ tile_excl,
-                                                          uint64_t *__restrict__ fin, uint32_t *__restrict__ out32, uint64_t cap_words,
-                                                          uint64_t *__restrict__ seq_start, uint32_t *__restrict__ raw_flag,
-                                                          uint64_t max_records, uint8_t *__restrict__ out8, uint64_t reads_cap,
-                                                          const uint64_t *__restrict__ frag_off)
+
+// What a tile publishes for its successors, one 64-bit word at a time (bit 63 = the word is there; the words are zeroed
+// before the launch).  Every word validates itself, so relaxed device-scope loads and stores are all the ordering needed.
+//   agg     the tile's summary: cA, cB, cC in 15 bits each (<= 16384), h in 14 (a header takes two bytes), ev, kind
+//   p0, p1  the reader state BEHIND the tile: (kind, ev, headers so far) and the sequence bytes so far
+struct Desc { unsigned long long agg, p0, p1, pad; };
+constexpr unsigned long long D_VALID = 1ull << 63;
+static_assert(ING_TILE <= 16384, "summary counts of a tile in 15 bits");
+__device__ __forceinline__ unsigned long long enc_agg(const Sum &s)
+{
+    return D_VALID | ((unsigned long long)s.kind << 61) | ((unsigned long long)s.ev << 59) | ((unsigned long long)s.h << 45) |
+           ((unsigned long long)s.cC << 30) | ((unsigned long long)s.cB << 15) | (unsigned long long)s.cA;
+}
+__device__ __forceinline__ Sum dec_agg(unsigned long long v)
+{
+    Sum s;
+    s.cA = (uint32_t)v & 0x7fffu; s.cB = (uint32_t)(v >> 15) & 0x7fffu; s.cC = (uint32_t)(v >> 30) & 0x7fffu;
+    s.h = (uint32_t)(v >> 45) & 0x3fffu; s.ev = (uint32_t)(v >> 59) & 3u; s.kind = (uint32_t)(v >> 61) & 3u;
+    return s;
+}
+__device__ __forceinline__ Pre dec_pre(unsigned long long p0, unsigned long long p1)
+{
+    Pre r;
+    r.h = p0 & ((1ull << 59) - 1); r.ev = (uint32_t)(p0 >> 59) & 3u; r.kind = (uint32_t)(p0 >> 61) & 3u;
+    r.cnt = p1 & ~D_VALID;
+    return r;
+}
+__device__ __forceinline__ unsigned long long ld_desc(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_desc(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// the state a tile starts in = the state behind the tile in front of it (after the kernel: plain loads)
+__device__ __forceinline__ Pre tile_entry_state(const Desc *__restrict__ desc, uint64_t t)
+{
+    return t ? dec_pre(desc[t - 1].p0, desc[t - 1].p1) : Pre{0, 0, 0, 0};
+}
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int l)
+{
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, l, WAVE), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), l, WAVE);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Decoupled look-back of one wave: lane i looks at tile t-1-i (then 64 further back, ...).  The nearest tile whose end
+// state is published gives the start; the summaries of the tiles between it and t are applied on top, in text order.
+// Tiles are taken in index order by blocks that are all resident (or dispatched in index order), so the tile this
+// wave waits for is always being worked on; should that ever fail, the wave gives up after LOOKBACK_SPINS polls and the
+// call fails with OPAL_EHIP instead of hanging.
+constexpr uint32_t LOOKBACK_SPINS = 1u << 20;
+__device__ __forceinline__ Pre look_back(const Desc *desc, uint64_t t, int lane, uint64_t *fin)
+{
+    Sum acc = sum_identity();                 // the tiles between the window and t (wave-uniform)
+    int64_t base = (int64_t)t - 1;
+    uint32_t spins = 0;
+    for (;;) {
+        const int64_t idx = base - lane;
+        unsigned long long a = 0, p0 = D_VALID, p1 = D_VALID;    // in front of the text: the reader's initial state
+        if (idx >= 0) {
+            p0 = ld_desc(&desc[idx].p0);
+            p1 = ld_desc(&desc[idx].p1);
+            a = ld_desc(&desc[idx].agg);
+        }
+        const bool has_p = ((p0 & p1) >> 63) != 0, has_a = (a >> 63) != 0;
+        const uint64_t bp = __ballot(has_p), bn = __ballot(!has_p && !has_a);
+        const int j = bp ? __builtin_ctzll(bp) : WAVE;           // the nearest tile with a published end state
+        const uint64_t between = j == WAVE ? ~0ull : ((1ull << j) - 1ull);
+        if (bn & between) {                                      // a tile in between has published nothing yet
+            if (++spins > LOOKBACK_SPINS) {
+                if (lane == 0) fin[F_STALL] = 1;
+                return Pre{0, 0, 0, 0};
+            }
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        Sum v = lane < j ? dec_agg(a) : sum_identity();
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {                     // lane + d holds the EARLIER tile: it goes first
+            Sum o;
+            const uint32_t st = (uint32_t)__shfl_down((int)(v.ev | (v.kind << 2)), d, WAVE);
+            o.h = (uint32_t)__shfl_down((int)v.h, d, WAVE);
+            o.ev = st & 3u; o.kind = st >> 2;
+            o.cA = (uint32_t)__shfl_down((int)v.cA, d, WAVE);
+            o.cB = (uint32_t)__shfl_down((int)v.cB, d, WAVE);
+            o.cC = (uint32_t)__shfl_down((int)v.cC, d, WAVE);
+            if (lane + d < WAVE) v = sum_combine(o, v);
+        }
+        Sum win;
+        win.h = (uint32_t)__shfl((int)v.h, 0, WAVE); win.ev = (uint32_t)__shfl((int)v.ev, 0, WAVE); win.kind = (uint32_t)__shfl((int)v.kind, 0, WAVE);
+        win.cA = (uint32_t)__shfl((int)v.cA, 0, WAVE); win.cB = (uint32_t)__shfl((int)v.cB, 0, WAVE); win.cC = (uint32_t)__shfl((int)v.cC, 0, WAVE);
+        acc = sum_combine(win, acc);
+        if (j < WAVE) return pre_apply(dec_pre(shfl64(p0, j), shfl64(p1, j)), acc);
+        base -= WAVE;
+    }
+}
+
+// a tile's share of the (at most two) dwords of the packed stream that it may have in common with its neighbours
+struct Edge { uint64_t g0; uint32_t nd, first, last; };
+
+// 2-bit codes of all sequence bytes into the packed stream out32 (base p of the concatenated sequence in bits 2*(p&15) of
+// dword p>>4), seq_start[r] for every header, raw_flag[r] for every record that holds a byte outside ACGT.
+__global__ __launch_bounds__(BLOCK) void ing_fused_kernel(const uint8_t *__restrict__ text, uint64_t n, uint64_t ntiles, Desc *desc,
+                                                           Edge *__restrict__ edges, uint64_t *__restrict__ fin, uint32_t *__restrict__ out32,
+                                                           uint64_t cap_words, uint64_t *__restrict__ seq_start,
+                                                           uint32_t *__restrict__ raw_flag, uint64_t max_records)
 {
     __shared__ Sum s_w[WPB];
-    __shared__ uint32_t s_bits[RAWCOPY ? 1 : ING_LDS_WORDS];
-    if (!RAWCOPY)
+    __shared__ uint32_t s_bits[ING_LDS_WORDS];
+    __shared__ Pre s_tp;
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    {
+        const uint64_t t = blockIdx.x;
         for (int i = threadIdx.x; i < ING_LDS_WORDS; i += BLOCK) s_bits[i] = 0;   // ordered by the scan's barriers
-    const uint64_t base = (uint64_t)blockIdx.x * ING_TILE + (uint64_t)threadIdx.x * ING_THREAD_BYTES;
-    uint32_t x[CPT][4];
-    Masks m[CPT];
-    const Sum mine = analyse_thread(text, n, base, x, m);
-    Sum total;
-    const Sum excl = block_excl_scan_sum(mine, s_w, total);
-    const Pre tp = pre_apply(seg_pre[blockIdx.x / SEG_TILES], tile_excl[blockIdx.x]);   // the state this tile starts in
-    const Pre in = pre_apply(tp, excl);
-    const bool open = in.ev != 2u, open_a = open && in.kind == 3u;
-    const uint64_t H = fin[F_H];
-    uint64_t cnt = in.cnt, hrun = in.h;
-    uint32_t lpos = (uint32_t)(tp.cnt & 15u) + (uint32_t)(in.cnt - tp.cnt);
-    static_for<CPT>([&](auto ci) {
-        constexpr int c = decltype(ci)::value;
-        const uint32_t CM = m[c].mC | (open ? m[c].mB : 0u) | (open_a ? m[c].mA : 0u);
-        const uint64_t h_in = hrun;                                   // headers in front of this chunk
-        if (!RAWCOPY) {
-            uint32_t hd = m[c].HD;
-            while (hd) {
-                const uint32_t bit = hd & (0u - hd);
-                hd ^= bit;
-                const uint64_t r = hrun++;
-                if (r < max_records) seq_start[r] = cnt + (uint32_t)__builtin_popcount(CM & (bit - 1u));
-            }
+        const uint64_t base = t * ING_TILE + (uint64_t)threadIdx.x * ING_THREAD_BYTES;
+        uint32_t x[CPT][4];
+        Masks m[CPT];
+        const Sum mine = analyse_thread(text, n, base, x, m);
+        Sum total;
+        const Sum excl = block_excl_scan_sum(mine, s_w, total);
+        if (wv == 0 && lane == 0) st_desc(&desc[t].agg, enc_agg(total));
+        // what does not depend on the state the tile starts in, while the predecessors publish: the 2-bit codes and the
+        // bytes outside ACGT of every chunk (the text bytes themselves are not needed after this)
+        uint32_t codes_c[CPT], bad_c[CPT];
+        static_for<CPT>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
             uint32_t q[4], nzb[4];
 #pragma unroll
             for (int d = 0; d < 4; d++) {
@@ -436,16 +505,50 @@ __global__ __launch_bounds__(BLOCK) void ing_pack_kernel(const uint8_t *__restri
                 const uint32_t diff = x[c][d] ^ __builtin_amdgcn_perm(0u, 0x54474341u, q[d]);     // "ACGT"[code] == byte ?
                 nzb[d] = ((((diff & 0x7f7f7f7fu) + 0x7f7f7f7fu) | diff) >> 7) & 0x01010101u;        // 1 in every byte outside ACGT
             }
-            uint32_t codes = gather_fields(q[0], q[1], q[2], q[3]);
-            uint32_t bad = gather_fields(nzb[0], nzb[1], nzb[2], nzb[3]);
+            codes_c[c] = gather_fields(q[0], q[1], q[2], q[3]);
+            bad_c[c] = gather_fields(nzb[0], nzb[1], nzb[2], nzb[3]);
+        });
+        if (wv == 0) {
+            const Pre tp0 = t ? look_back(desc, t, lane, fin) : Pre{0, 0, 0, 0};
+            if (lane == 0) {
+                const Pre end = pre_apply(tp0, total);
+                st_desc(&desc[t].p0, D_VALID | ((unsigned long long)end.kind << 61) | ((unsigned long long)end.ev << 59) | end.h);
+                st_desc(&desc[t].p1, D_VALID | end.cnt);
+                s_tp = tp0;
+                if (t == ntiles - 1) {
+                    fin[F_H] = end.h;
+                    fin[F_T] = end.cnt;
+                    fin[F_CURSOR] = (((end.cnt + 3) / 4) + 15) & ~15ull;   // raw records go behind the packed stream
+                }
+            }
+        }
+        __syncthreads();
+        const Pre tp = s_tp;                                                   // the state this tile starts in
+        const Pre in = pre_apply(tp, excl);
+        const bool open = in.ev != 2u, open_a = open && in.kind == 3u;
+        uint64_t cnt = in.cnt, hrun = in.h;
+        uint32_t lpos = (uint32_t)(tp.cnt & 15u) + (uint32_t)(in.cnt - tp.cnt);
+        bool prebad = false;
+        static_for<CPT>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            const uint32_t CM = m[c].mC | (open ? m[c].mB : 0u) | (open_a ? m[c].mA : 0u);
+            const uint64_t h_in = hrun;                                   // headers in front of this chunk
+            uint32_t hd = m[c].HD;
+            while (hd) {
+                const uint32_t bit = hd & (0u - hd);
+                hd ^= bit;
+                const uint64_t r = hrun++;
+                if (r < max_records) seq_start[r] = cnt + (uint32_t)__builtin_popcount(CM & (bit - 1u));
+            }
+            uint32_t codes = codes_c[c], bad = bad_c[c];
             bad &= CM;
             uint64_t last_r = ~0ull;
             while (bad) {
                 const uint32_t bit = bad & (0u - bad);
                 bad ^= bit;
                 const uint64_t hh = h_in + (uint32_t)__builtin_popcount(m[c].HD & (bit - 1u));
-                if (hh == 0 && H != 0) continue;                       // text before the first header
-                const uint64_t r = hh ? hh - 1 : 0;
+                if (hh == 0) { prebad = true; continue; }              // in front of the first header: record 0 only if there is none
+                const uint64_t r = hh - 1;
                 if (r == last_r || r >= max_records) continue;
                 last_r = r;
                 if (__atomic_load_n(&raw_flag[r], __ATOMIC_RELAXED) == 0u && atomicExch(&raw_flag[r], 1u) == 0u)
@@ -460,50 +563,90 @@ __global__ __launch_bounds__(BLOCK) void ing_pack_kernel(const uint8_t *__restri
             }
             lpos += nf;
             cnt += nf;
-        } else {
-            // the chunk's sequence bytes, one record (stretch between headers) at a time
-            uint32_t hd = m[c].HD, from = 0xffffffffu;
-            uint64_t hcur = h_in;
-            while (CM) {
-                const uint32_t nb = hd & (0u - hd);                     // next header in the chunk (0: none)
-                uint32_t seg = CM & from & (nb - 1u);
-                if (seg && (hcur != 0 || H == 0)) {
-                    const uint64_t r = hcur ? hcur - 1 : 0;
-                    if (r < max_records && raw_flag[r]) {
-                        const uint64_t dst0 = frag_off[r] + (cnt - seq_start[r]);
-                        while (seg) {
-                            const uint32_t bit = seg & (0u - seg);
-                            seg ^= bit;
-                            const uint64_t dst = dst0 + (uint32_t)__builtin_popcount(CM & (bit - 1u));
-                            if (dst < reads_cap) out8[dst] = (uint8_t)chunk_byte(x[c], (uint32_t)__builtin_ctz(bit) >> 1);
-                        }
-                    }
-                }
-                if (!nb) break;
-                hd ^= nb;
-                from = ~(nb - 1u);
-                hcur++;
-            }
-            hrun += (uint32_t)__builtin_popcount(m[c].HD);
-            cnt += (uint32_t)__builtin_popcount(CM);
-        }
-    });
-    if (!RAWCOPY) {
+        });
+        if (prebad) fin[F_PREBAD] = 1;                                       // plain store of a constant
         __syncthreads();
         const uint64_t tot = pre_apply(tp, total).cnt - tp.cnt;
         const uint64_t g0 = tp.cnt >> 4;
         const uint32_t nd = (uint32_t)(((tp.cnt & 15u) + tot + 15u) >> 4);
-        for (uint32_t i = threadIdx.x; i < nd; i += BLOCK) {
-            const uint32_t v = s_bits[i];
-            if (g0 + i >= cap_words) continue;
-            if (i == 0 || i == nd - 1) { if (v) atomicOr(&out32[g0 + i], v); }   // dwords shared with a neighbouring tile
-            else out32[g0 + i] = v;
-        }
+        // interior dwords hold bases of this tile only; the first and the last may be shared with neighbouring tiles
+        for (uint32_t i = threadIdx.x + 1u; i + 1u < nd; i += BLOCK)
+            if (g0 + i < cap_words) out32[g0 + i] = s_bits[i];
+        if (threadIdx.x == 0) edges[t] = Edge{g0, nd, nd ? s_bits[0] : 0u, nd > 1u ? s_bits[nd - 1u] : 0u};
     }
 }
 
-// ---- pass 4: records ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void ing_records_kernel(const uint64_t *__restrict__ seq_start, const uint32_t *__restrict__ raw_flag,
+// The shared dwords: zeroed (ZERO), then every tile's share OR-ed in.  One thread per tile.
+template <bool ZERO>
+__global__ __launch_bounds__(BLOCK) void ing_edges_kernel(const Edge *__restrict__ edges, uint64_t ntiles, uint32_t *__restrict__ out32,
+                                                           uint64_t cap_words)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= ntiles) return;
+    const Edge e = edges[t];
+    if (e.nd == 0) return;
+    const uint64_t gl = e.g0 + e.nd - 1;
+    if (ZERO) {
+        if (e.g0 < cap_words) out32[e.g0] = 0u;
+        if (gl < cap_words) out32[gl] = 0u;
+    } else {
+        if (e.first && e.g0 < cap_words) atomicOr(&out32[e.g0], e.first);
+        if (e.last && gl < cap_words) atomicOr(&out32[gl], e.last);
+    }
+}
+
+// ---- raw records: the bytes of the records flagged raw to out8[frag_off[r] + i] (a second pass over the text, only when
+// such records exist)
+__global__ __launch_bounds__(BLOCK) void ing_rawcopy_kernel(const uint8_t *__restrict__ text, uint64_t n, const Desc *__restrict__ desc,
+                                                             const uint64_t *__restrict__ fin, const uint64_t *__restrict__ seq_start,
+                                                             const uint32_t *__restrict__ raw_flag, uint64_t max_records,
+                                                             uint8_t *__restrict__ out8, uint64_t reads_cap,
+                                                             const uint64_t *__restrict__ frag_off)
+{
+    __shared__ Sum s_w[WPB];
+    const uint64_t base = (uint64_t)blockIdx.x * ING_TILE + (uint64_t)threadIdx.x * ING_THREAD_BYTES;
+    uint32_t x[CPT][4];
+    Masks m[CPT];
+    const Sum mine = analyse_thread(text, n, base, x, m);
+    Sum total;
+    const Sum excl = block_excl_scan_sum(mine, s_w, total);
+    const Pre in = pre_apply(tile_entry_state(desc, blockIdx.x), excl);
+    const bool open = in.ev != 2u, open_a = open && in.kind == 3u;
+    const uint64_t H = fin[F_H];
+    uint64_t cnt = in.cnt, hrun = in.h;
+    static_for<CPT>([&](auto ci) {
+        constexpr int c = decltype(ci)::value;
+        uint32_t CM = m[c].mC | (open ? m[c].mB : 0u) | (open_a ? m[c].mA : 0u);
+        // the chunk's sequence bytes, one record (stretch between headers) at a time
+        uint32_t hd = m[c].HD, from = 0xffffffffu;
+        uint64_t hcur = hrun;
+        while (CM) {
+            const uint32_t nb = hd & (0u - hd);                     // next header in the chunk (0: none)
+            uint32_t seg = CM & from & (nb - 1u);
+            if (seg && (hcur != 0 || H == 0)) {
+                const uint64_t r = hcur ? hcur - 1 : 0;
+                if (r < max_records && raw_flag[r]) {
+                    const uint64_t dst0 = frag_off[r] + (cnt - seq_start[r]);
+                    while (seg) {
+                        const uint32_t bit = seg & (0u - seg);
+                        seg ^= bit;
+                        const uint64_t dst = dst0 + (uint32_t)__builtin_popcount(CM & (bit - 1u));
+                        if (dst < reads_cap) out8[dst] = (uint8_t)chunk_byte(x[c], (uint32_t)__builtin_ctz(bit) >> 1);
+                    }
+                }
+            }
+            if (!nb) break;
+            hd ^= nb;
+            from = ~(nb - 1u);
+            hcur++;
+        }
+        hrun += (uint32_t)__builtin_popcount(m[c].HD);
+        cnt += (uint32_t)__builtin_popcount(CM);
+    });
+}
+
+// ---- records ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void ing_records_kernel(const uint64_t *__restrict__ seq_start, uint32_t *__restrict__ raw_flag,
                                                              uint64_t *__restrict__ fin, uint64_t max_records, uint64_t reads_cap,
                                                              uint64_t *__restrict__ frag_off, uint32_t *__restrict__ frag_len)
 {
@@ -516,6 +659,10 @@ __global__ __launch_bounds__(BLOCK) void ing_records_kernel(const uint64_t *__re
         const uint64_t e = (r + 1 < n_rec) ? seq_start[r + 1] : T;
         const uint64_t len = e - s;
         if (H && r == n_rec - 1 && len == 0) { fin[F_DROPPED] = 1; continue; }   // fasta_functions.py:20-22
+        if (H == 0 && fin[F_PREBAD]) {                         // a text without any header is one record: all of it counts
+            raw_flag[0] = 1u;
+            fin[F_NRAW] = 1;
+        }
         const bool raw = raw_flag[r] != 0;
         if (len > 0x7fffffffull) fin[F_TOOLONG] = 1;           // plain stores of a constant
         const uint32_t l31 = len > 0x7fffffffull ? 0x7fffffffu : (uint32_t)len;
@@ -542,7 +689,7 @@ int grow(opal_ctx *ctx, void **p, uint64_t *cap, uint64_t need)
 
 }  // namespace
 
-// scratch of passes 1-2 inside ctx->ing_tiles: [segment states | fin | per-tile prefixes | tile summaries | segment totals]
+// scratch of opal_ingest_scan inside ctx->ing_tiles: [segment states | fin | per-tile prefixes | tile summaries | segment totals]
 struct IngScratch {
     Pre *seg_pre;
     uint64_t *fin;
@@ -561,10 +708,34 @@ static IngScratch ing_layout(void *base, uint64_t ntiles)
     L.bytes = L.nseg * (sizeof(Pre) + sizeof(Sum)) + F_WORDS * sizeof(uint64_t) + 2 * ntiles * sizeof(Sum) + 256;
     return L;
 }
-
-// passes 1-2: tile summaries and the state every tile starts in; fin[F_H], fin[F_T], fin[F_CURSOR] are set
-static int ingest_scan_passes(opal_ctx *ctx, const uint8_t *d_text, uint64_t nbytes, uint64_t ntiles)
+// scratch of opal_ingest_fasta inside ctx->ing_tiles: [fin | tile descriptors | tile edges]
+struct FusedScratch {
+    uint64_t *fin;
+    Desc *desc;
+    Edge *edges;
+    uint64_t bytes;
+};
+static FusedScratch fused_layout(void *base, uint64_t ntiles)
 {
+    FusedScratch L;
+    L.fin = (uint64_t *)base;
+    L.desc = (Desc *)(L.fin + F_WORDS);
+    L.edges = (Edge *)(L.desc + ntiles);
+    L.bytes = F_WORDS * sizeof(uint64_t) + ntiles * (sizeof(Desc) + sizeof(Edge)) + 256;
+    return L;
+}
+
+extern "C" int opal_ingest_scan(opal_ctx *ctx, const uint8_t *d_text, uint64_t nbytes, uint64_t *n_headers_out, uint64_t *seq_bytes_out)
+{
+    if (!ctx) return opal::fail(nullptr, OPAL_EINVAL, "opal_ingest_scan: null ctx");
+    if (!n_headers_out || !seq_bytes_out) return opal::fail(ctx, OPAL_EINVAL, "opal_ingest_scan: null count outputs");
+    *n_headers_out = 0;
+    *seq_bytes_out = 0;
+    if (nbytes == 0) return OPAL_OK;
+    if (!d_text) return opal::fail(ctx, OPAL_EINVAL, "opal_ingest_scan: null device pointer");
+    OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint64_t ntiles = (nbytes + ING_TILE - 1) / ING_TILE;
+    if (ntiles > 0x7fffffffull) return opal::fail(ctx, OPAL_EINVAL, "opal_ingest_scan: text too large for one call (32 TiB)");
     const IngScratch S = ing_layout(nullptr, ntiles);
     int rc = grow(ctx, &ctx->ing_tiles, &ctx->ing_tiles_cap, S.bytes);
     if (rc) return rc;
@@ -574,31 +745,11 @@ static int ingest_scan_passes(opal_ctx *ctx, const uint8_t *d_text, uint64_t nby
     hipLaunchKernelGGL(ing_scan_local_kernel, dim3((unsigned)L.nseg), dim3(BLOCK), 0, ctx->stream, L.tile_sum, ntiles, L.tile_excl, L.seg_sum);
     hipLaunchKernelGGL(ing_scan_kernel, dim3(1), dim3(SC_BLOCK), 0, ctx->stream, L.seg_sum, L.nseg, L.seg_pre, L.fin);
     OPAL_HIP_CHECK(ctx, hipGetLastError());
-    return OPAL_OK;
-}
-
-extern "C" int opal_ingest_scan(opal_ctx *ctx, const uint8_t *d_text, uint64_t nbytes, uint64_t *n_headers_out, uint64_t *seq_bytes_out)
-{
-    if (!ctx) return opal::fail(nullptr, OPAL_EINVAL, "opal_ingest_scan: null ctx");
-    if (!n_headers_out || !seq_bytes_out) return opal::fail(ctx, OPAL_EINVAL, "opal_ingest_scan: null count outputs");
-    *n_headers_out = 0;
-    *seq_bytes_out = 0;
-    ctx->ing_scan_valid = false;
-    if (nbytes == 0) return OPAL_OK;
-    if (!d_text) return opal::fail(ctx, OPAL_EINVAL, "opal_ingest_scan: null device pointer");
-    OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    const uint64_t ntiles = (nbytes + ING_TILE - 1) / ING_TILE;
-    if (ntiles > 0x7fffffffull) return opal::fail(ctx, OPAL_EINVAL, "opal_ingest_scan: text too large for one call (32 TiB)");
-    int rc = ingest_scan_passes(ctx, d_text, nbytes, ntiles);
-    if (rc) return rc;
     uint64_t host[2];
-    OPAL_HIP_CHECK(ctx, hipMemcpyAsync(host, ing_layout(ctx->ing_tiles, ntiles).fin, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+    OPAL_HIP_CHECK(ctx, hipMemcpyAsync(host, L.fin, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
     OPAL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     *n_headers_out = host[F_H];
     *seq_bytes_out = host[F_T];
-    ctx->ing_scan_valid = true;
-    ctx->ing_scan_text = d_text;
-    ctx->ing_scan_nbytes = nbytes;
     return OPAL_OK;
 }
 
@@ -607,8 +758,6 @@ extern "C" int opal_ingest_fasta(opal_ctx *ctx, const uint8_t *d_text, uint64_t 
                                  uint64_t *reads_bytes_out)
 {
     if (!ctx) return opal::fail(nullptr, OPAL_EINVAL, "opal_ingest_fasta: null ctx");
-    const bool scanned = ctx->ing_scan_valid && ctx->ing_scan_text == d_text && ctx->ing_scan_nbytes == nbytes;
-    ctx->ing_scan_valid = false;                                  // a scan serves the one call that follows it
     if (!n_records_out || !reads_bytes_out) return opal::fail(ctx, OPAL_EINVAL, "opal_ingest_fasta: null count outputs");
     *n_records_out = 0;
     *reads_bytes_out = 0;
@@ -620,26 +769,26 @@ extern "C" int opal_ingest_fasta(opal_ctx *ctx, const uint8_t *d_text, uint64_t 
     hipStream_t st = ctx->stream;
     const uint64_t ntiles = (nbytes + ING_TILE - 1) / ING_TILE;
     if (ntiles > 0x7fffffffull) return opal::fail(ctx, OPAL_EINVAL, "opal_ingest_fasta: text too large for one call (32 TiB)");
-    // scratch: [tile states | fin | tile summaries] (passes 1-2), [record starts | raw flags]
     int rc = grow(ctx, &ctx->ing_rec, &ctx->ing_rec_cap, (max_records + 1) * (sizeof(uint64_t) + sizeof(uint32_t)) + 256);
     if (rc) return rc;
-    if (!scanned) {
-        rc = ingest_scan_passes(ctx, d_text, nbytes, ntiles);
-        if (rc) return rc;
-    }
-    const IngScratch L = ing_layout(ctx->ing_tiles, ntiles);
+    rc = grow(ctx, &ctx->ing_tiles, &ctx->ing_tiles_cap, fused_layout(nullptr, ntiles).bytes);
+    if (rc) return rc;
+    const FusedScratch L = fused_layout(ctx->ing_tiles, ntiles);
     uint64_t *fin = L.fin;
     uint64_t *seq_start = (uint64_t *)ctx->ing_rec;
     uint32_t *raw_flag = (uint32_t *)(seq_start + (max_records + 1));
     uint32_t *out32 = reinterpret_cast<uint32_t *>(d_reads_out);
     const uint64_t cap_words = reads_cap / 4;
-    // the packed stream is assembled with atomic ORs where tiles meet: those dwords start as zero
-    hipLaunchKernelGGL(ing_zero_edges_kernel, dim3((unsigned)((ntiles + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, L.seg_pre, L.tile_excl, ntiles,
-                       fin, out32, cap_words);
+    // fin and the descriptors start as zero ("nothing published yet")
+    OPAL_HIP_CHECK(ctx, hipMemsetAsync(fin, 0, F_WORDS * sizeof(uint64_t) + ntiles * sizeof(Desc), st));
     OPAL_HIP_CHECK(ctx, hipMemsetAsync(seq_start, 0, sizeof(uint64_t), st));   // a file without any '>' is one record that starts at 0
     OPAL_HIP_CHECK(ctx, hipMemsetAsync(raw_flag, 0, max_records * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(ing_pack_kernel<false>, dim3((unsigned)ntiles), dim3(BLOCK), 0, st, d_text, nbytes, L.seg_pre, L.tile_excl, fin, out32, cap_words,
-                       seq_start, raw_flag, max_records, d_reads_out, reads_cap, d_frag_off);
+    const unsigned fgrid = (unsigned)ntiles;
+    hipLaunchKernelGGL(ing_fused_kernel, dim3(fgrid), dim3(BLOCK), 0, st, d_text, nbytes, ntiles, L.desc, L.edges, fin, out32, cap_words,
+                       seq_start, raw_flag, max_records);
+    const unsigned egrid = (unsigned)((ntiles + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(ing_edges_kernel<true>, dim3(egrid), dim3(BLOCK), 0, st, L.edges, ntiles, out32, cap_words);
+    hipLaunchKernelGGL(ing_edges_kernel<false>, dim3(egrid), dim3(BLOCK), 0, st, L.edges, ntiles, out32, cap_words);
     const int rgrid = (int)std::max<uint64_t>(1, std::min<uint64_t>((max_records + BLOCK - 1) / BLOCK, (uint64_t)ctx->num_cus * 8));
     hipLaunchKernelGGL(ing_records_kernel, dim3(rgrid), dim3(BLOCK), 0, st, seq_start, raw_flag, fin, max_records, reads_cap, d_frag_off,
                        d_frag_len);
@@ -647,17 +796,25 @@ extern "C" int opal_ingest_fasta(opal_ctx *ctx, const uint8_t *d_text, uint64_t 
     uint64_t host[F_WORDS];
     OPAL_HIP_CHECK(ctx, hipMemcpyAsync(host, fin, sizeof(host), hipMemcpyDeviceToHost, st));
     OPAL_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if (host[F_STALL]) return opal::fail(ctx, OPAL_EHIP, "opal_ingest_fasta: a tile waited for its predecessors in vain (scan chain stalled)");
     const uint64_t H = host[F_H], T = host[F_T];
-    if (H > max_records) return opal::fail(ctx, OPAL_ERANGE, "opal_ingest_fasta: more records than max_records");
+    // too small a buffer: the counts the caller needs for a second call come back through the two outputs
+    if (H > max_records) {
+        *n_records_out = H;                // (which records are raw is not known for those beyond max_records: bytes unknown, 0)
+        return opal::fail(ctx, OPAL_ERANGE, "opal_ingest_fasta: more records than max_records");
+    }
     if (host[F_TOOLONG]) return opal::fail(ctx, OPAL_EINVAL, "opal_ingest_fasta: a record is longer than 2^31-1 bases");
     const uint64_t n_rec = (H ? H : (T ? 1 : 0)) - (host[F_DROPPED] ? 1 : 0);
     *n_records_out = n_rec;
     if (n_rec == 0) return OPAL_OK;
     const uint64_t out_bytes = host[F_NRAW] ? host[F_CURSOR] : ((T + 3) / 4 + 3) & ~3ull;
-    if (out_bytes > reads_cap || host[F_OVERFLOW]) return opal::fail(ctx, OPAL_ERANGE, "opal_ingest_fasta: d_reads_out too small");
+    if (out_bytes > reads_cap || host[F_OVERFLOW]) {
+        *reads_bytes_out = out_bytes;      // (the cursor has run over every raw record: this is what the text needs)
+        return opal::fail(ctx, OPAL_ERANGE, "opal_ingest_fasta: d_reads_out too small");
+    }
     if (host[F_NRAW]) {
-        hipLaunchKernelGGL(ing_pack_kernel<true>, dim3((unsigned)ntiles), dim3(BLOCK), 0, st, d_text, nbytes, L.seg_pre, L.tile_excl, fin, out32, cap_words,
-                           seq_start, raw_flag, max_records, d_reads_out, reads_cap, d_frag_off);
+        hipLaunchKernelGGL(ing_rawcopy_kernel, dim3((unsigned)ntiles), dim3(BLOCK), 0, st, d_text, nbytes, L.desc, fin, seq_start, raw_flag,
+                           max_records, d_reads_out, reads_cap, d_frag_off);
         OPAL_HIP_CHECK(ctx, hipGetLastError());
         OPAL_HIP_CHECK(ctx, hipStreamSynchronize(st));
     }

@@ -42,9 +42,6 @@ struct opal_ctx {
     // scratch of the FASTA ingest (grown on demand)
     void *ing_tiles = nullptr, *ing_rec = nullptr;
     uint64_t ing_tiles_cap = 0, ing_rec_cap = 0;
-    bool ing_scan_valid = false;             // opal_ingest_scan ran on (ing_scan_text, ing_scan_nbytes) and nothing used it yet
-    const void *ing_scan_text = nullptr;
-    uint64_t ing_scan_nbytes = 0;
     std::string err;
 };
 

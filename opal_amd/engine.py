@@ -385,18 +385,20 @@ class Engine:
             if n == 0:
                 return self.upload(PackedReads.from_sequences([]))
             d_text = t.from_numpy(arr.copy() if not arr.flags.writeable else arr).to(self.device)
-        nh, nseq = C.c_uint64(), C.c_uint64()
-        check(lib().opal_ingest_scan(self._h, d_text.data_ptr(), n, C.byref(nh), C.byref(nseq)), self._h)
-        max_rec, T = max(int(nh.value), 1), int(nseq.value)
-        off = t.empty(max_rec, dtype=t.int64, device=self.device)
-        ln = t.empty(max_rec, dtype=t.int32, device=self.device)
+        # the call reads the text once and needs no sizes in advance: buffers for records of >= 96 bytes of text each and
+        # for a few raw records first; a call that finds them too small reports what the text needs (OPAL_ERANGE)
         nrec, nb = C.c_uint64(), C.c_uint64()
-        # room for the packed stream and a few raw records first; the full bound only if that turns out too small
-        for cap in (T // 4 + T // 32 + 4096, T // 4 + T + 64):
+        max_rec, cap = n // 96 + 1024, n // 4 + n // 32 + 4096
+        for _ in range(3):
+            off = t.empty(max_rec, dtype=t.int64, device=self.device)
+            ln = t.empty(max_rec, dtype=t.int32, device=self.device)
             reads = t.empty(cap, dtype=t.uint8, device=self.device)
             rc = lib().opal_ingest_fasta(self._h, d_text.data_ptr(), n, reads.data_ptr(), cap, off.data_ptr(), ln.data_ptr(), max_rec,
                                          C.byref(nrec), C.byref(nb))
             if rc != _lib.OPAL_ERANGE:
                 break
+            max_rec, cap = max(max_rec, int(nrec.value), 1), max(cap, int(nb.value))
         check(rc, self._h)
+        if int(nrec.value) * 2 < max_rec:                          # hand the unused part of the optimistic buffers back
+            off, ln = off[:int(nrec.value)].clone(), ln[:int(nrec.value)].clone()
         return DeviceBatch(reads, off, ln, int(nrec.value), max(int(nb.value), 1))

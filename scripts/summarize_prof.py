@@ -41,10 +41,10 @@ def main(out):
         if vals:
             res[ctr + "_KiB_per_launch"] = sum(vals) / len(vals)
             res[ctr + "_launches"] = len(vals)
-    if not hot and any("ing_summary_kernel" in n for n in stats):
+    if not hot and any("ing_fused_kernel" in n for n in stats):
         # FASTA ingest: several kernels per call; counters are summed over them and divided by the number of calls
-        res["kernel"] = "ing_summary_kernel + ing_scan_local_kernel + ing_scan_kernel + ing_pack_kernel + ing_records_kernel"
-        calls = int(next(r for n, r in stats.items() if "ing_summary_kernel" in n)["Calls"])
+        res["kernel"] = "ing_fused_kernel + ing_edges_kernel x2 + ing_records_kernel"
+        calls = int(next(r for n, r in stats.items() if "ing_fused_kernel" in n)["Calls"])
         res["calls"] = calls
         res["avg_kernel_ms"] = sum(float(r["TotalDurationNs"]) for n, r in stats.items() if "::ing_" in n) / calls / 1e6
         for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
@@ -52,7 +52,7 @@ def main(out):
             for r in rows(os.path.join(out, sub, "**", "*counter_collection.csv")):
                 if r.get("Counter_Name") == ctr and "::ing_" in r["Kernel_Name"]:
                     tot += float(r["Counter_Value"])
-                    launches += "ing_summary_kernel" in r["Kernel_Name"]
+                    launches += "ing_fused_kernel" in r["Kernel_Name"]
             if launches:
                 res[ctr + "_KiB_per_launch"] = tot / launches
                 res[ctr + "_launches"] = launches

@@ -415,8 +415,8 @@ def test_gpu_fasta_ingest_matches_reference_reader(amd, eng, oracle, golden_dir)
     genomes = (b">short1\nACGTACGT\n>g1 packed genome\n" + wrapped(g1) + b">empty\n>g2 raw genome\n" + wrapped(bytes(g2), 61) +
                b">short2\nacgtn\n>g3\n" + wrapped(g3, 80) + b">edge\n" + wrapped(bytes(rng.choice(ACGT, size=65_536))))
     _check_ingest(amd, eng, oracle, genomes)
-    # the C-ABI without opal_ingest_scan in front (the call then runs all passes itself), an exact-fit and a too-small
-    # d_reads_out, too few record slots
+    # the C-ABI directly: an exact-fit and a too-small d_reads_out, too few record slots (OPAL_ERANGE reports what the text
+    # needs), and opal_ingest_scan's counts
     import ctypes as C
     import torch
     from opal_amd._lib import OPAL_ERANGE, lib
@@ -432,14 +432,19 @@ def test_gpu_fasta_ingest_matches_reference_reader(amd, eng, oracle, golden_dir)
                                      C.byref(nrec), C.byref(nb))
         assert rc == want_rc, (cap, rc)
         assert bool((reads[cap:] == 0xEE).all())                # never writes past reads_cap
+        assert nrec.value == ref.n and nb.value == ref.nbytes    # also what a failed call reports
         if rc == 0:
-            assert nrec.value == ref.n and nb.value == ref.nbytes
             got = amd.PackedReads(reads.cpu().numpy()[:nb.value], off.cpu().numpy()[:ref.n].view(np.uint64),
                                   ln.cpu().numpy()[:ref.n].view(np.uint32))
             assert got.sequences() == [sq for _, sq in oracle.fasta_read(big, universal_newlines=True)]
     rc = lib().opal_ingest_fasta(eng._h, d_text.data_ptr(), len(big), reads.data_ptr(), len(big) * 2, off.data_ptr(), ln.data_ptr(), 100,
                                  C.byref(nrec), C.byref(nb))
-    assert rc == OPAL_ERANGE
+    assert rc == OPAL_ERANGE and nrec.value == big.count(b">rec") and nb.value == 0
+    nh, ns = C.c_uint64(), C.c_uint64()
+    assert lib().opal_ingest_scan(eng._h, d_text.data_ptr(), len(big), C.byref(nh), C.byref(ns)) == 0
+    seqs_big = [sq for _, sq in oracle.fasta_read(big, universal_newlines=True)]
+    assert nh.value == len(seqs_big) == ref.n
+    assert ns.value == sum(len(sq) for sq in seqs_big) + len(b"junk before the first header")   # dropped text sits in the stream too
     # a text pointer that is not 16-byte aligned (every thread then loads byte by byte), an unaligned output pointer
     shifted = torch.empty(len(big) + 16, dtype=torch.uint8, device=eng.device)
     for sh in (1, 7):
