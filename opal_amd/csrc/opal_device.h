@@ -438,6 +438,28 @@ __device__ __forceinline__ uint64_t next_chunk(unsigned long long *queue, int la
     return ((uint64_t)hi << 32) | lo;
 }
 
+// Work distribution of kernels whose work items are short (emit: ~8 us per fragment; the deterministic learner: one example
+// or one slot range per draw).  The queue counter is ONE address and same-address atomics retire at ~83 M/s on
+// this GPU (12 ns each): a wave's first draw and its last (the one that tells it the queue is empty) were 2 x 8192 atomics =
+// ~200 us per launch, most of a 200k-fragment batch.  So: wave w owns chunk w outright (no atomic), the counter hands out
+// the chunks after those, and a wave looks at the counter with a plain coherent load first and leaves without an atomic
+// when it is already past the end.
+__device__ __forceinline__ uint64_t first_chunk(int wv, uint64_t qchunk)
+{
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane(wv);   // threadIdx.x / 64 is a VGPR to the compiler: keep the loop scalar
+    return ((uint64_t)blockIdx.x * WPB + (uint64_t)w) * qchunk;
+}
+__device__ __forceinline__ uint64_t next_chunk_after(unsigned long long *queue, int lane, uint64_t qchunk, uint64_t n)
+{
+    const uint64_t base = (uint64_t)gridDim.x * WPB * qchunk;
+    unsigned long long v = 0;
+    if (base >= n) return n;   // the waves' own chunks cover the batch: nobody touches the counter
+    if (lane == 0) v = atomicAdd(queue, (unsigned long long)qchunk);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return base + (((uint64_t)hi << 32) | lo);
+}
+
 // ------------------------------------------------------------------------------------------ phase S
 template <int VEC> struct VecOf;
 template <> struct VecOf<1> { using type = float; };

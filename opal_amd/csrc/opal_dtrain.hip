@@ -90,7 +90,7 @@ __global__ __launch_bounds__(BLOCK) void dtrain_score_kernel(Batch B, Geom G, co
     uint32_t *hb = s_hb[wv];
     const uint32_t Ku = (uint32_t)K;
     const bool reg_on = (ta.l1 != 0.0f) || (ta.l2 != 0.0f);
-    for (uint64_t e = next_chunk(queue, lane, 1); e < gn; e = next_chunk(queue, lane, 1)) {
+    for (uint64_t e = first_chunk(wv, 1); e < gn; e = next_chunk_after(queue, lane, 1, gn)) {
         const uint64_t frag = e0 + e;
         const uint32_t label = (uint32_t)(labels[frag] - 1);
         const uint32_t kbase = (uint32_t)(foff[frag] - foff[e0]);
@@ -243,10 +243,11 @@ __global__ __launch_bounds__(BLOCK) void dtrain_apply_kernel(float *__restrict__
                                                               const float *__restrict__ sfac, DArgs ta, unsigned long long *__restrict__ queue)
 {
     const int lane = threadIdx.x & (WAVE - 1);
+    const int wv = threadIdx.x / WAVE;
     const uint32_t Ku = (uint32_t)K;
     const bool reg = (ta.l1 != 0.0f) || (ta.l2 != 0.0f);
     const uint32_t nq = (NP - colour + 1u) / 2u;                 // partitions of this colour
-    for (uint64_t q = next_chunk(queue, lane, 1); q < nq; q = next_chunk(queue, lane, 1)) {
+    for (uint64_t q = first_chunk(wv, 1); q < nq; q = next_chunk_after(queue, lane, 1, nq)) {
         const uint32_t p = colour + 2u * (uint32_t)q;
         const uint32_t i0 = pstart[p], i1 = pstart[p + 1];
         for (uint32_t i = i0; i < i1; i++) {

@@ -292,27 +292,6 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l)
     return ((uint64_t)hi << 32) | lo;
 }
 
-// Work distribution of the emit kernels.  The queue counter is ONE address and same-address atomics retire at ~83 M/s on
-// this GPU (12 ns each): a wave's first draw and its last (the one that tells it the queue is empty) were 2 x 8192 atomics =
-// ~200 us per launch, most of a 200k-fragment batch.  So: wave w owns chunk w outright (no atomic), the counter hands out
-// the chunks after those, and a wave looks at the counter with a plain coherent load first and leaves without an atomic
-// when it is already past the end.
-__device__ __forceinline__ uint64_t emit_first_chunk(int wv, uint64_t qchunk)
-{
-    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane(wv);   // threadIdx.x / 64 is a VGPR to the compiler: keep the loop scalar
-    return ((uint64_t)blockIdx.x * WPB + (uint64_t)w) * qchunk;
-}
-__device__ __forceinline__ uint64_t emit_next_chunk(unsigned long long *queue, int lane, uint64_t qchunk, uint64_t n)
-{
-    const uint64_t base = (uint64_t)gridDim.x * WPB * qchunk;
-    unsigned long long v = 0;
-    if (base >= n) return n;   // the waves' own chunks cover the batch: nobody touches the counter
-    if (lane == 0) v = atomicAdd(queue, (unsigned long long)qchunk);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-    return base + (((uint64_t)hi << 32) | lo);
-}
-
 // Adds the fragments a block of the fast kernels left over into queue[2]: per block, not per wave (8192 same-address atomics
 // are 90 us, which is what a launch over an all-text batch cost for taking nothing).
 __device__ __forceinline__ void emit_report_left(uint32_t *s_left, uint32_t left, int lane, unsigned long long *queue)
@@ -390,7 +369,7 @@ __global__ __launch_bounds__(BLOCK) void emit_canon2_kernel(Batch B, Geom G, uin
     const uint32_t zfa = sgpr((uint32_t)(uintptr_t)zw), zra = zfa + EF_ZLEN * 4u;
     const uint32_t S = G.reverse ? 2u : 1u;
     uint32_t left = 0;
-    for (uint64_t q0 = emit_first_chunk(wv, qchunk); q0 < B.n; q0 = emit_next_chunk(queue, lane, qchunk, B.n)) {
+    for (uint64_t q0 = first_chunk(wv, qchunk); q0 < B.n; q0 = next_chunk_after(queue, lane, qchunk, B.n)) {
         const uint64_t mine = q0 + (uint64_t)lane;
         uint64_t o0 = 0, off = 0;
         uint32_t lw = 0;
@@ -446,7 +425,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     if (FAST && threadIdx.x == 0) s_left = 0;
     fill_kmer4_table(s_tab);
     uint32_t left = 0;
-    for (uint64_t q0 = emit_first_chunk(wv, qchunk); q0 < B.n; q0 = emit_next_chunk(queue + (FAST ? 0 : 1), lane, qchunk, B.n)) {
+    for (uint64_t q0 = first_chunk(wv, qchunk); q0 < B.n; q0 = next_chunk_after(queue + (FAST ? 0 : 1), lane, qchunk, B.n)) {
         const uint64_t mine = q0 + (uint64_t)lane;
         uint64_t o0 = 0, off = 0;
         uint32_t lw = 0;
