@@ -314,6 +314,10 @@ __device__ __forceinline__ void canon2_step(uint32_t bf, uint32_t br, bool on_rc
     const char *tabc = reinterpret_cast<const char *>(tab);
     // (tried: pattern 1's four lookups from a copy of the table in global memory, through the otherwise idle L1, to take
     // them off the LDS: 3.97 -> 4.93 ms; a 64-lane dword gather costs the vector cache far more than the LDS's conflicts)
+    // (tried: 32 bank-private copies of the table, entry e of copy c at dword 32 e + c, lane l reading copy l & 31, in blocks
+    // of 12-16 waves that share the 32 KB: SQ_LDS_BANK_CONFLICT 6.7e8 -> 0 and SQ_LDS_IDX_ACTIVE -33 % as predicted, but the
+    // address shifts and the second table recomputed in registers add 18 % VALU instructions, and at most 6 waves per SIMD
+    // stay resident: 3.905 ms against 3.915, i.e. nothing; with 14-16 waves per block 4.5-4.8 ms)
     auto T = [&](uint32_t a) { return *reinterpret_cast<const uint32_t *>(tabc + a); };
     uint32_t x[8], x0;
     const uint32_t qa[8] = {q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7]};
