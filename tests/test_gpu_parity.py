@@ -471,6 +471,17 @@ def test_gpu_fasta_ingest_matches_reference_reader(amd, eng, oracle, golden_dir)
     assert np.array_equal(c1.cpu().numpy(), c2.cpu().numpy())
 
 
+def test_gpu_fasta_ingest_resizes_when_its_guess_is_too_small(amd, eng, oracle):
+    """Engine.ingest_fasta sizes its buffers by guess (one record per >= 96 bytes of text, few raw records) and repeats the
+    call with the sizes OPAL_ERANGE reports: many tiny records, and records that are all raw."""
+    tiny = b">r\nAC\n" * 200_000                                  # 1.2 MB, 200 000 records: 15 x the guess
+    _check_ingest(amd, eng, oracle, tiny)
+    raw = b"".join(b">r%d\n" % i + b"acgtn" * 40 + b"\n" for i in range(20_000))   # every record raw: 4 MB behind the stream
+    _check_ingest(amd, eng, oracle, raw)
+    both = b"".join(b">x\nacgu\n" for _ in range(150_000))          # too many records AND all of them raw
+    _check_ingest(amd, eng, oracle, both)
+
+
 def test_gpu_fasta_ingest_at_scale(amd, eng):
     """A 150 MB reads file (more tiles than one round of the tile scan holds, so the carried state is exercised) with
     1000 raw records sprinkled in: every packed record is its 200-base view of the stream, every raw one decodes."""
