@@ -187,7 +187,7 @@ class Bench:
             total = int(offsets[-1].item())
             out_idx = t.empty(total, dtype=t.int32, device=dev)
             from opal_amd._lib import check, lib
-            info.update(kernel="emit_idx_kernel", keep=(gs, offsets, out_idx))
+            info.update(kernel="emit_canon2_kernel", keep=(gs, offsets, out_idx))
 
             def step():
                 check(lib().opal_features(eng._h, batch.data.data_ptr(), batch.nbytes, batch.off.data_ptr(), batch.len.data_ptr(),
