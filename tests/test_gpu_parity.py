@@ -471,6 +471,22 @@ def test_gpu_fasta_ingest_matches_reference_reader(amd, eng, oracle, golden_dir)
     assert np.array_equal(c1.cpu().numpy(), c2.cpu().numpy())
 
 
+def test_gpu_fasta_ingest_chain_across_tiles(amd, eng, oracle):
+    """Texts of 5-40 tiles (16 KiB each) whose structure is hostile to the chained scan: lines, headers, '+' blocks and CR LF
+    pairs that straddle tile borders, long stretches without any line start, tiles without a single sequence byte."""
+    rng = np.random.default_rng(int(os.environ.get("OPAL_FUZZ_SEED", "321")))
+    pieces = [b"ACGT" * 50, b"acgtn" * 30, b"N" * 100, b"\n", b"\r\n", b"\r", b">", b">name with words\n", b"+\n", b"\n+\n",
+              b"\n>h\n", b"I" * 3000, b"ACGT" * 5000, b">" + b"x" * 20000 + b"\n", b"+" + b"q" * 17000 + b"\n", b"\n" * 300]
+    for trial in range(int(os.environ.get("OPAL_CHAIN_TRIALS", "12"))):
+        target = int(rng.integers(5, 40)) * 16384 + int(rng.integers(-20, 20))
+        parts, size = [], 0
+        while size < target:
+            piece = pieces[int(rng.integers(0, len(pieces)))]
+            parts.append(piece)
+            size += len(piece)
+        _check_ingest(amd, eng, oracle, b"".join(parts)[:target])
+
+
 def test_gpu_fasta_ingest_resizes_when_its_guess_is_too_small(amd, eng, oracle):
     """Engine.ingest_fasta sizes its buffers by guess (one record per >= 96 bytes of text, few raw records) and repeats the
     call with the sizes OPAL_ERANGE reports: many tiny records, and records that are all raw."""
