@@ -17,7 +17,12 @@ int fail(opal_ctx *ctx, int code, const std::string &msg)
 }
 }  // namespace opal
 
-extern "C" const char *opal_version(void) { return "opal_hip 0.1 (gfx950)"; }
+// OPAL_SRC_HASH: sha256 (first 16 hex digits) over the library's sources and headers, passed by __graft_entry__.build();
+// tests compare it with the tree so that a library built from other sources than the ones beside it is noticed
+#ifndef OPAL_SRC_HASH
+#define OPAL_SRC_HASH "unknown"
+#endif
+extern "C" const char *opal_version(void) { return "opal_hip 0.2 (gfx950) src " OPAL_SRC_HASH; }
 
 extern "C" const char *opal_last_error(const opal_ctx *ctx) { return ctx ? ctx->err.c_str() : opal::g_err.c_str(); }
 

@@ -27,6 +27,10 @@ def test_cabi_exports_every_declared_symbol():
         assert hasattr(L, name), "libopal_hip.so lacks " + name
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
     assert b"gfx950" in L.opal_version()
+    # the library beside the sources was built from exactly these sources (a stale or experimental build would otherwise
+    # travel to the GPU box unnoticed)
+    import __graft_entry__ as entry
+    assert L.opal_version().decode().endswith("src " + entry.source_hash()), "opal_amd/libopal_hip.so is stale: run __graft_entry__.build()"
 
 
 def test_product_fasta_reader_and_rc_match_reference(golden_dir):
