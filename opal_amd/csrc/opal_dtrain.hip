@@ -286,39 +286,79 @@ __global__ __launch_bounds__(BLOCK) void dtrain_apply_kernel(float *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------ phase C
-// The constant row: one thread per class, the group's examples in order, accumulators in registers.
-__global__ __launch_bounds__(64) void dtrain_const_kernel(float *__restrict__ w, float *__restrict__ g2, uint32_t mask, int K, uint32_t crow,
-                                                           const float *__restrict__ upd, const float *__restrict__ gsq,
-                                                           const float *__restrict__ sfac, uint32_t gn, DArgs ta)
+// The constant row: one lane per class, the group's examples in order, accumulators in registers.  The chain over the
+// examples is serial, so what counts is how fast one wave gets (upd, gsq) of the next example: straight from memory the
+// loop waited 100 ns per example even with 32 examples' loads in flight (0.83 ms per group of 8192, a tenth of the
+// group's time and a fifth in later passes).  Here three waves of the block stream tiles of CT examples x 64 classes
+// into LDS, one tile ahead, and the fourth wave runs the chain out of LDS.  Same operations in the same order per class.
+constexpr int CT = 32;                 // examples per tile: 2 buffers x 2 arrays x 32 x 64 floats = 32 KiB of LDS
+constexpr int CT_LOADERS = 192;        // threads of waves 1-3
+__global__ __launch_bounds__(256) void dtrain_const_kernel(float *__restrict__ w, float *__restrict__ g2, uint32_t mask, int K, uint32_t crow,
+                                                            const float *__restrict__ upd, const float *__restrict__ gsq,
+                                                            const float *__restrict__ sfac, uint32_t gn, DArgs ta)
 {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= (uint32_t)K) return;
+    __shared__ float s_u[2][CT][WAVE], s_q[2][CT][WAVE], s_s[2][CT];
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    const uint32_t c0 = blockIdx.x * WAVE, c = c0 + (uint32_t)lane;
+    const uint32_t Ku = (uint32_t)K;
     const bool reg = (ta.l1 != 0.0f) || (ta.l2 != 0.0f);
-    const size_t slot = (size_t)((crow + c) & mask);
-    float Gc = g2[slot], Wc = w[slot];
-    constexpr uint32_t UN = 32;   // loads of 32 examples in flight per thread: the loop is latency-bound (one wave per 64 classes)
-    uint32_t e = 0;
-    for (; e + UN <= gn; e += UN) {
-        float u[UN], q[UN], s[UN];
+    const uint32_t ntile = (gn + CT - 1) / CT;
+    auto load_tile = [&](uint32_t tile, int buf) {          // waves 1-3: all loads first, then the LDS stores
+        constexpr int PER = (CT * WAVE + CT_LOADERS - 1) / CT_LOADERS;
+        const uint32_t e0 = tile * CT, t0 = threadIdx.x - WAVE;
+        float u[PER], q[PER];
 #pragma unroll
-        for (uint32_t x = 0; x < UN; x++) { u[x] = upd[(uint64_t)(e + x) * K + c]; q[x] = gsq[(uint64_t)(e + x) * K + c]; s[x] = sfac[e + x]; }
-#pragma unroll
-        for (uint32_t x = 0; x < UN; x++) {
-            if (!reg && q[x] == 0.0f && u[x] == 0.0f) continue;
-            Gc += q[x];
-            const float d = (Gc > 0.0f) ? u[x] * rsq(Gc) : 0.0f;
-            Wc = step_w(Wc, d, reg, 1.0f - s[x] * ta.l2, s[x] * ta.l1);
+        for (int k = 0; k < PER; k++) {
+            const uint32_t i = t0 + (uint32_t)k * CT_LOADERS, ex = i / WAVE, cl = i % WAVE;
+            const bool on = i < CT * WAVE && e0 + ex < gn && c0 + cl < Ku;
+            u[k] = on ? upd[(uint64_t)(e0 + ex) * Ku + c0 + cl] : 0.0f;
+            q[k] = on ? gsq[(uint64_t)(e0 + ex) * Ku + c0 + cl] : 0.0f;
         }
+        const float sv = (t0 < CT && e0 + t0 < gn) ? sfac[e0 + t0] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const uint32_t i = t0 + (uint32_t)k * CT_LOADERS;
+            if (i < CT * WAVE) { s_u[buf][i / WAVE][i % WAVE] = u[k]; s_q[buf][i / WAVE][i % WAVE] = q[k]; }
+        }
+        if (t0 < CT) s_s[buf][t0] = sv;
+    };
+    const size_t slot = (size_t)((crow + min(c, Ku - 1u)) & mask);
+    float Gc = 0.0f, Wc = 0.0f;
+    if (wv == 0) { Gc = g2[slot]; Wc = w[slot]; }
+    else if (ntile) load_tile(0, 0);
+    __syncthreads();
+    for (uint32_t tile = 0; tile < ntile; tile++) {
+        const int buf = (int)(tile & 1u);
+        if (wv != 0) {
+            if (tile + 1 < ntile) load_tile(tile + 1, buf ^ 1);
+        } else {
+            // branch-free, eight examples at a time out of registers: the only serial dependences are one add for G and an
+            // add + select for w per example (with a branch per example every step paid the LDS and rsq latencies: 100 ns)
+            const uint32_t cnt = min((uint32_t)CT, gn - tile * CT);
+            for (uint32_t x0 = 0; x0 < cnt; x0 += 8) {
+                float u[8], q[8], sx[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {               // rows past cnt (the group's last tile) were filled with zeros
+                    const uint32_t x = min(x0 + (uint32_t)k, (uint32_t)CT - 1u);
+                    u[k] = s_u[buf][x][lane]; q[k] = s_q[buf][x][lane]; sx[k] = s_s[buf][x];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const bool off = x0 + (uint32_t)k >= cnt || (!reg && q[k] == 0.0f && u[k] == 0.0f);   // a step that is skipped
+                    const float Gn = Gc + q[k];
+                    const float d = (Gn > 0.0f) ? u[k] * rsq(Gn) : 0.0f;
+                    const float Wn = step_w(Wc, d, reg, 1.0f - sx[k] * ta.l2, sx[k] * ta.l1);
+                    Gc = Gn;                                 // a skipped step has q = 0: G + 0 is G
+                    Wc = off ? Wc : Wn;
+                }
+            }
+        }
+        __syncthreads();
     }
-    for (; e < gn; e++) {
-        const float u = upd[(uint64_t)e * K + c], q = gsq[(uint64_t)e * K + c], s = sfac[e];
-        if (!reg && q == 0.0f && u == 0.0f) continue;
-        Gc += q;
-        const float d = (Gc > 0.0f) ? u * rsq(Gc) : 0.0f;
-        Wc = step_w(Wc, d, reg, 1.0f - s * ta.l2, s * ta.l1);
+    if (wv == 0 && c < Ku) {
+        g2[slot] = Gc;
+        w[slot] = Wc;
     }
-    g2[slot] = Gc;
-    w[slot] = Wc;
 }
 
 __global__ void dtrain_mirror_kernel(float *w, uint64_t n_slots, uint32_t pad)
@@ -495,7 +535,7 @@ int opal::train_batch_groups(opal_ctx *ctx, const uint8_t *d_reads, uint64_t rea
             }
         }
         // C: the constant row, examples in order
-        hipLaunchKernelGGL(dtrain_const_kernel, dim3((K + 63) / 64), dim3(64), 0, ctx->stream, w, g2, mask, K, crow, (const float *)upd,
+        hipLaunchKernelGGL(dtrain_const_kernel, dim3((K + 63) / 64), dim3(256), 0, ctx->stream, w, g2, mask, K, crow, (const float *)upd,
                            (const float *)gsq, (const float *)sfac, gn, ta);
         OPAL_HIP_CHECK(ctx, hipGetLastError());
     }
