@@ -45,6 +45,9 @@ WORKLOADS = {
                         desc="1564 classes, 12.5M x 200bp fragments per GPU (= 100M over 8 GPUs), numHash=1, -r, b=31"),
     "cfg4_numhash4": dict(K=1564, n=1_000_000, pattern="patterns_k64_t16_m4_s7.txt", bits=31, mode="predict",
                           desc="1564 classes, numHash=4 (P=5, F=1370), 1M x 200bp fragments, -r, b=31"),
+    "numhash8_default": dict(K=1564, n=500_000, pattern="patterns_k64_t16_m8_s7.txt", bits=31, mode="predict",
+                             desc="the reference CLI's default --num-hash 8 (P=9, F=2466): 1564 classes, 500k x 200bp fragments, -r, b=31 "
+                                  "(not a BASELINE config; --workload only)"),
     "cfg5_emit": dict(K=1564, n=4_000_000, pattern="patterns_k64_t16_m1_s7.txt", bits=31, mode="emit",
                       desc="training-feature generation: sample 200bp fragments from 1564 HBM-resident genomes (zero-copy views) "
                            "and emit their hashed features, numHash=1, -r"),
