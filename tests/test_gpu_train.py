@@ -133,7 +133,9 @@ def test_concurrent_training_with_regularisation_keeps_the_shared_row(amd, golde
         eng.close()
     for v in out.values():
         assert v[0] > 0.05 and np.all(v[1:] < -0.05)
-    assert np.allclose(out["conc_reg"], out["conc"], rtol=0.1), (out["conc_reg"], out["conc"])
+    # both runs are Hogwild (how stale the bias is that an example reads depends on timing: 0.150 against 0.167 has been seen);
+    # a lost-update bug leaves the regularised row an order of magnitude short
+    assert np.allclose(out["conc_reg"], out["conc"], rtol=0.35), (out["conc_reg"], out["conc"])
 
 
 def _make_genomes(rng, n_genomes, glen, divergence):
