@@ -315,14 +315,22 @@ def main():
     ap.add_argument("--nfrag", type=int, default=0, help="override fragments per GPU")
     ap.add_argument("--bits", type=int, default=0, help="override table bits")
     ap.add_argument("--classes", type=int, default=0, help="override the class count K (experiments)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling on BASELINE configs[2]: the whole 100 M-fragment, 1564-class job split over the ranks "
+                         "(100 M / N fragments per rank, one step = the job; use --steps 1 --warmup 0 at small N)")
     ap.add_argument("--no-extra", action="store_true", help="time the headline workload only (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=300_000)
     args = ap.parse_args()
 
     B = Bench(args)
+    if args.strong:
+        args.workload, args.no_extra = "cfg3_1564sp", True
     overridden = bool(args.nfrag or args.bits or args.classes)
     wl = dict(WORKLOADS[args.workload])
+    if args.strong:
+        wl["n"] = -(-100_000_000 // B.world)                 # the last fragments of an uneven split are scored twice: never fewer than the job
+        wl["desc"] = "1564 classes, 100M x 200bp fragments split over %d GPU(s), numHash=1, -r, b=31 (strong scaling)" % B.world
     if args.nfrag:
         wl["n"] = args.nfrag
     if args.bits:
@@ -330,9 +338,9 @@ def main():
     if args.classes:
         wl["K"] = args.classes
 
-    head, info = B.measure(args.workload, wl, args.steps, args.warmup, None if overridden else args.workload)
+    head, info = B.measure(args.workload, wl, args.steps, args.warmup, None if overridden or args.strong else args.workload)
     res = {"metric": "fragments/sec", "value": head["value"], "unit": "fragments/s", "n_gpus": B.world, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+           "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
            "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic (uniform ACGT fragments generated on the device from a seed)",
            "config": head["config"], "hashes_per_s": head["hashes_per_s"], "kernel": head["kernel"], "roofline": head["roofline"],
            "per_rank_ms_per_step": head["per_rank_ms_per_step"]}
