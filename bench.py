@@ -324,7 +324,7 @@ def main():
                          "(100 M / N fragments per rank, one step = the job; use --steps 1 --warmup 0 at small N)")
     ap.add_argument("--no-extra", action="store_true", help="time the headline workload only (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=300_000)
+    ap.add_argument("--cpu-sample", type=int, default=600_000)
     args = ap.parse_args()
 
     B = Bench(args)
