@@ -52,10 +52,10 @@ constexpr uint64_t EMIT_QCHUNK = 32;   // fragments per draw from the work queue
 // Lanes own consecutive windows, so every gather is `ds_read_addtid_b32` (address = M0 + 4*lane, no address VGPR, no
 // VALU): the wave-uniform part (window step + pattern position) goes through M0 on the scalar unit.  Hashes go straight
 // from registers to HBM (lane u writes features u*P .. u*P+P-1: contiguous across the wave), no LDS hash buffer.
-constexpr int EF_MAXLEN = 256;           // bases per strand
+constexpr int EF_MAXLEN = 512;           // bases per strand (2 x 250/300-bp reads included; 19 KiB of LDS per block of 4 waves still leaves the 7 blocks per CU the registers allow)
 constexpr int EF_ZLEN = EF_MAXLEN + 64;  // Z dwords per strand: lanes past the last window read (and discard) up to 63 entries further
-constexpr int EF_PKLEN = 24;             // packed dwords per strand: one zero dword in front (Z[0] starts 2 bits before base 0), 17 of data, slack
-                                         // (the Z build reads up to entry 21: whole iterations of 64)
+constexpr int EF_PKLEN = 40;             // packed dwords per strand: one zero dword in front (Z[0] starts 2 bits before base 0), 33 of data, slack
+                                         // (the Z build reads up to entry 37: whole iterations of 64)
 constexpr int EF_WAVE_BYTES = 2 * SEQB + HB_EMIT * 4;   // per-wave LDS of the generic kernel (strands + hash buffer)
 
 // Reads Z[lane + (base + q_i)/4] for wave-uniform byte offsets.  M0 is written one instruction before the read that uses it
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(BLOCK) void emit_canon2_kernel(Batch B, Geom G, uin
 // amdgpu_waves_per_eu(8, 8): the generic walker fits 64 VGPRs without spilling when told to (left alone the compiler takes 77
 // and loses two waves per SIMD: the text path fell from 327 M to 229 M fragments/s)
 template <bool FAST>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void emit_idx_kernel(Batch B, Geom G, uint32_t mask, const uint64_t *__restrict__ out_off,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FAST ? 7 : 8, 8))) void emit_idx_kernel(Batch B, Geom G, uint32_t mask, const uint64_t *__restrict__ out_off,
                                                           uint32_t *__restrict__ out_idx, uint64_t out_cap,
                                                           unsigned long long *__restrict__ queue, uint64_t qchunk, int fast_ran)
 {
