@@ -460,6 +460,39 @@ __device__ __forceinline__ uint64_t next_chunk_after(unsigned long long *queue, 
     return base + (((uint64_t)hi << 32) | lo);
 }
 
+// The emit kernels draw 10^5 chunks per launch, and ONE counter serves 83 M draws/s: a launch that finds nothing to do in its
+// chunks (the fast kernel over a batch of long reads) still paid 12 ns per chunk, 1 ms at 1.3 M fragments.  Eight counters a
+// cache line apart share the chunks behind the waves' own: counter r hands out the r-th eighth, a wave starts at counter
+// (its number mod 8) and moves on to the next one when a counter has run out, until all eight have.
+// Words of ctx->d_queue: [0] the one counter of the kernels that use next_chunk(), [Q_LEFT] fragments the emit fast kernel
+// left to the generic one, [Q_SUBQ_FAST + 16 r], [Q_SUBQ_GENERIC + 16 r] the emit kernels' counters, [Q_BAD] out-of-buffer
+// fragments seen since the last opal_sync (outside the range that is cleared per launch).
+constexpr int SUBQ = 8, SUBQ_WORDS = 16;
+enum { Q_LEFT = 2, Q_SUBQ_FAST = 16, Q_SUBQ_GENERIC = Q_SUBQ_FAST + SUBQ * SUBQ_WORDS, Q_BAD = Q_SUBQ_GENERIC + SUBQ * SUBQ_WORDS, Q_WORDS = 512 };
+struct SubQ { uint32_t r, tried; };                       // a wave's cursor over the counters (wave-uniform)
+__device__ __forceinline__ SubQ subq_start(int wv)
+{
+    return SubQ{(uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * WPB + (uint32_t)wv) % SUBQ)), 0u};
+}
+__device__ __forceinline__ uint64_t next_chunk_subq(unsigned long long *subq, int lane, uint64_t qchunk, uint64_t n, SubQ &st)
+{
+    const uint64_t base = (uint64_t)gridDim.x * WPB * qchunk;
+    if (base >= n) return n;                               // the waves' own chunks cover the batch: nobody touches a counter
+    const uint64_t nch = (n - base + qchunk - 1) / qchunk; // chunks behind the waves' own
+    const uint64_t per = (nch + SUBQ - 1) / SUBQ;
+    while (st.tried < (uint32_t)SUBQ) {
+        unsigned long long v = 0;
+        if (lane == 0) v = atomicAdd(subq + st.r * SUBQ_WORDS, 1ull);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+        const uint64_t c = ((uint64_t)hi << 32) | lo, ch = (uint64_t)st.r * per + c;
+        if (c < per && ch < nch) return base + ch * qchunk;
+        st.r = (st.r + 1u) % (uint32_t)SUBQ;               // this counter has run out
+        st.tried++;
+    }
+    return n;
+}
+
 // ------------------------------------------------------------------------------------------ phase S
 template <int VEC> struct VecOf;
 template <> struct VecOf<1> { using type = float; };

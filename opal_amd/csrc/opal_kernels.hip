@@ -298,7 +298,7 @@ __device__ __forceinline__ void emit_report_left(uint32_t *s_left, uint32_t left
 {
     if (left && lane == 0) atomicAdd(s_left, left);
     __syncthreads();
-    if (threadIdx.x == 0 && *s_left) atomicAdd(queue + 2, (unsigned long long)*s_left);
+    if (threadIdx.x == 0 && *s_left) atomicAdd(queue + Q_LEFT, (unsigned long long)*s_left);
 }
 
 // ---- The canonical Opal geometry with numHash = 1 (ldpc.py: pattern 0 = a run of 16 positions, pattern 1 = one LDPC row;
@@ -373,7 +373,8 @@ __global__ __launch_bounds__(BLOCK) void emit_canon2_kernel(Batch B, Geom G, uin
     const uint32_t zfa = sgpr((uint32_t)(uintptr_t)zw), zra = zfa + EF_ZLEN * 4u;
     const uint32_t S = G.reverse ? 2u : 1u;
     uint32_t left = 0;
-    for (uint64_t q0 = first_chunk(wv, qchunk); q0 < B.n; q0 = next_chunk_after(queue, lane, qchunk, B.n)) {
+    SubQ sq = subq_start(wv);
+    for (uint64_t q0 = first_chunk(wv, qchunk); q0 < B.n; q0 = next_chunk_subq(queue + Q_SUBQ_FAST, lane, qchunk, B.n, sq)) {
         const uint64_t mine = q0 + (uint64_t)lane;
         uint64_t o0 = 0, off = 0;
         uint32_t lw = 0;
@@ -424,12 +425,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FAST ? 7 
     __shared__ uint32_t s_tab[KTAB];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = threadIdx.x / WAVE;
-    if (!FAST && fast_ran && __builtin_nontemporal_load(queue + 2) == 0ull) return;   // block-uniform: nothing was left over
+    if (!FAST && fast_ran && __builtin_nontemporal_load(queue + Q_LEFT) == 0ull) return;   // block-uniform: nothing was left over
     __shared__ uint32_t s_left;
     if (FAST && threadIdx.x == 0) s_left = 0;
     fill_kmer4_table(s_tab);
     uint32_t left = 0;
-    for (uint64_t q0 = first_chunk(wv, qchunk); q0 < B.n; q0 = next_chunk_after(queue + (FAST ? 0 : 1), lane, qchunk, B.n)) {
+    SubQ sq = subq_start(wv);
+    for (uint64_t q0 = first_chunk(wv, qchunk); q0 < B.n; q0 = next_chunk_subq(queue + (FAST ? Q_SUBQ_FAST : Q_SUBQ_GENERIC), lane, qchunk, B.n, sq)) {
         const uint64_t mine = q0 + (uint64_t)lane;
         uint64_t o0 = 0, off = 0;
         uint32_t lw = 0;
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FAST ? 7 
                 if (locate_fragment(B, frag).len == 0) {
                     const uint64_t cnt = feature_count(B.len[frag], G);
                     for (uint64_t j = lane; j < cnt; j += WAVE) dst[j] = 0xffffffffu;
-                    if (cnt && lane == 0) atomicAdd(queue + 3, 1ull);
+                    if (cnt && lane == 0) atomicAdd(queue + Q_BAD, 1ull);
                     continue;
                 }
                 uint32_t *hb = reinterpret_cast<uint32_t *>(s_wave[wv] + 2 * SEQB);
@@ -503,7 +505,7 @@ __global__ __launch_bounds__(BLOCK) void emit_names_kernel(Batch B, Geom G, cons
             const uint64_t o = out_off[frag], cnt = feature_count(B.len[frag], G);
             if (o <= out_cap && cnt <= out_cap - o) {
                 for (uint64_t j = lane; j < cnt * (uint64_t)t; j += WAVE) out_names[o * (uint64_t)t + j] = 0;
-                if (lane == 0) atomicAdd(queue + 3, 1ull);
+                if (lane == 0) atomicAdd(queue + Q_BAD, 1ull);
             }
             continue;
         }
@@ -825,8 +827,8 @@ extern "C" int opal_ctx_create(int device_id, void *stream, opal_ctx **out)
     // NULL is HIP's default (null) stream, which is also what torch.cuda.current_stream() is unless the caller
     // switched streams: work enqueued here is then ordered with the caller's copies without extra events.
     ctx->stream = (hipStream_t)stream;
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_queue, 256);
-    if (e == hipSuccess) e = hipMemset(ctx->d_queue, 0, 256);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_queue, Q_WORDS * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(ctx->d_queue, 0, Q_WORDS * sizeof(unsigned long long));
     if (e != hipSuccess) {
         std::string m = std::string("opal_ctx_create: ") + hipGetErrorString(e);
         delete ctx;
@@ -869,9 +871,9 @@ extern "C" int opal_sync(opal_ctx *ctx)
     OPAL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     // fragments of opal_features / opal_feature_names calls that reached outside their d_reads (queue word 3)
     unsigned long long bad = 0;
-    OPAL_HIP_CHECK(ctx, hipMemcpy(&bad, ctx->d_queue + 3, sizeof(bad), hipMemcpyDeviceToHost));
+    OPAL_HIP_CHECK(ctx, hipMemcpy(&bad, ctx->d_queue + Q_BAD, sizeof(bad), hipMemcpyDeviceToHost));
     if (bad) {
-        OPAL_HIP_CHECK(ctx, hipMemset(ctx->d_queue + 3, 0, sizeof(bad)));
+        OPAL_HIP_CHECK(ctx, hipMemset(ctx->d_queue + Q_BAD, 0, sizeof(bad)));
         return opal::fail(ctx, OPAL_EINVAL, std::to_string(bad) + " fragment(s) of the emit calls since the last opal_sync reach outside d_reads "
                                             "(offset + length beyond reads_bytes): their features were written as 0xffffffff / NUL names");
     }
@@ -1126,8 +1128,8 @@ extern "C" int opal_features(opal_ctx *ctx, const uint8_t *d_reads, uint64_t rea
         if (ctx->tune_qchunk || n > qmax * waves) return qmax;
         return (n + waves - 1) / waves;
     };
-    // queue words: [0] the fast kernel's work counter, [1] the generic kernel's, [2] fragments the fast kernel left over
-    OPAL_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_queue, 0, 3 * sizeof(unsigned long long), ctx->stream));
+    // the emit kernels' counters and the leftover count start at zero (opal_device.h: words of d_queue); Q_BAD lies behind them
+    OPAL_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_queue, 0, Q_BAD * sizeof(unsigned long long), ctx->stream));
     // the fast kernel reads the batch as dwords: it needs a 4-byte aligned buffer of at least two of them
     const int fast = ctx->d_fast && ctx->tune_emit_fast && (reinterpret_cast<uintptr_t>(d_reads) & 3u) == 0 && reads_bytes >= 8;
     int grid = 1;

@@ -1,0 +1,35 @@
+"""Emit rate by fragment length, fast path on and off (hashes/s make lengths comparable).
+Run on the GPU box:  python scripts/emit_len_bench.py"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import opal_amd as amd  # noqa: E402
+
+rng = np.random.default_rng(3)
+k = 64
+here = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(here, "..", "tests", "golden", "patterns_k64_t16_m1_s7.txt")) as f:
+    pos = amd.parse_patterns(f.readlines(), k)
+eng = amd.Engine(0)
+eng.set_patterns(pos, k)
+import sys
+for L in ([int(a) for a in sys.argv[1:]] or [100, 200, 250, 300, 512, 600]):
+    n = 800_000_000 // L
+    batch = eng.upload(amd.PackedReads.from_codes(rng.integers(0, 4, size=(n, L), dtype=np.uint8)))
+    for fast in (True, False):
+        eng.set_tuning(emit_fast=fast)
+        eng.features(batch, True, 31)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            idx, off = eng.features(batch, True, 31)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 5
+        print("L=%3d fast=%-5s %6.2f ms  %7.1f M fragments/s  %6.1f G hashes/s" % (L, fast, dt * 1e3, n / dt / 1e6, idx.numel() / dt / 1e9), flush=True)
+        del idx, off
+eng.set_tuning()
