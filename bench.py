@@ -48,9 +48,11 @@ WORKLOADS = {
     "numhash8_default": dict(K=1564, n=500_000, pattern="patterns_k64_t16_m8_s7.txt", bits=31, mode="predict",
                              desc="the reference CLI's default --num-hash 8 (P=9, F=2466): 1564 classes, 500k x 200bp fragments, -r, b=31 "
                                   "(not a BASELINE config; --workload only)"),
-    "cfg5_emit": dict(K=1564, n=4_000_000, pattern="patterns_k64_t16_m1_s7.txt", bits=31, mode="emit",
-                      desc="training-feature generation: sample 200bp fragments from 1564 HBM-resident genomes (zero-copy views) "
-                           "and emit their hashed features, numHash=1, -r"),
+    "cfg5_emit": dict(K=1564, n=31_280_000, genomes=1564, genome_len=4_000_000, coverage=1.0,
+                      pattern="patterns_k64_t16_m1_s7.txt", bits=31, mode="emit",
+                      desc="training-feature generation, one batch at coverage 1 (readme.txt:116-118: -c 1 --num-batches 15): 1564 genomes x 4 Mbp "
+                           "resident in HBM (1.56 GB packed), 31.28 M 200bp fragments drawn by the CPython-exact sampler as zero-copy views, "
+                           "shuffled (opal.py:363), hashed features emitted by ONE launch into one 68.6 GB index buffer, numHash=1, -r"),
     "train_356sp": dict(K=356, n=200_000, pattern="patterns_k64_t16_m1_s7.txt", bits=31, mode="train", cold=True,
                         desc="native OAA learner, worst case: first pass from a zeroed table (every class has a non-zero error, "
                              "nothing is skipped) over 200k labelled 200bp fragments, 356 classes, numHash=1, -r, b=31"),
@@ -96,9 +98,7 @@ class Bench:
         self.rank = int(os.environ.get("RANK", "0"))
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        if self.world != args.gpus:
-            if self.world == 1 and args.gpus > 1:
-                sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        if self.world != args.gpus:      # under a launcher the launcher's world size is the truth (main() starts one otherwise)
             args.gpus = self.world
         self.dist = None
         if self.world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:      # launched by torch.distributed.run (also with one rank)
@@ -183,9 +183,21 @@ class Bench:
             def step():
                 eng.predict(batch, True, want_scores=False, out_class=out_class)
         elif mode == "emit":
-            n_genomes, glen = max(K, 8), 200_000
+            n_genomes, glen = wl.get("genomes", max(K, 8)), wl.get("genome_len", 200_000)
             gs = self.device_genomes(n_genomes, glen, 1234)
-            batch, _ = self.views(gs, n, L, glen, n_genomes)
+            per_genome = -(-int(wl.get("coverage", 0.0) * glen) // L)
+            if n == n_genomes * per_genome:
+                # BASELINE configs[4]: the whole batch `drawfrag -c coverage` makes of these genomes (util/drawfrag.py:36-49:
+                # ceil(c*len/l) draws per genome, seed 42 + rank), in the shuffled order train() feeds (opal.py:363)
+                rng = self.amd.Rng(42 + self.rank)
+                gpos, ggen = rng.sample_positions([glen] * n_genomes, L, wl["coverage"])
+                assert len(gpos) == n, (len(gpos), n)
+                sel = rng.shuffle_perm(n).astype(np.int64)
+                batch = gs.fragments(gpos[sel], ggen[sel], L)
+                del gpos, ggen, sel
+            else:                                          # --nfrag: a part of that batch (rehearsals)
+                batch, _ = self.views(gs, n, L, glen, n_genomes)
+            info.update(genomes=n_genomes, genome_len=glen)
             offsets = eng.feature_offsets(batch, True)
             total = int(offsets[-1].item())
             out_idx = t.empty(total, dtype=t.int32, device=dev)
@@ -307,6 +319,9 @@ class Bench:
                           "kmer": KMER, "row_weight": 16, "patterns": info["P"], "reverse_complement": True, "bits": info["bits"],
                           "features_per_fragment": F,
                           "parallelism": "fragment-sharded x%d, replicated table, no collective" % self.world}}
+        if mode == "emit":
+            res["config"].update(genomes=info["genomes"], genome_len=info["genome_len"], coverage=n * L_FRAG / (info["genomes"] * info["genome_len"]),
+                                 packed_genome_bytes=info["genomes"] * info["genome_len"] // 4, index_buffer_bytes=4 * F * n)
         return res, info
 
 
@@ -326,6 +341,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=600_000)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))     # nothing has touched the GPU yet: the ranks are child processes
 
     B = Bench(args)
     if args.strong:
@@ -366,6 +384,28 @@ def main():
     if B.dist:
         B.dist.barrier()
         B.dist.destroy_process_group()
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: starts the N ranks itself, as CHILD processes of torch.distributed.run
+    (the same command line the driver uses), before this process has initialised the GPU; rank 0's JSON line goes to the
+    inherited stdout and the launcher's exit code is returned.  On a box with fewer GPUs than ranks the ranks share the
+    devices round-robin and rendezvous over gloo (a rehearsal of the N>1 path, not a measurement)."""
+    import socket
+    import subprocess
+    import torch
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    ndev = torch.cuda.device_count()          # counts devices without creating a GPU context
+    if ndev < n:
+        env.setdefault("OPAL_DIST_BACKEND", "gloo")
+        print("bench.py: %d GPU(s) for %d ranks: ranks share devices, rendezvous over gloo (rehearsal mode)" % (ndev, n), file=sys.stderr, flush=True)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def cpu_baseline(B, info, m):

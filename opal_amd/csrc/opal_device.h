@@ -512,18 +512,33 @@ __device__ __forceinline__ void vadd(float4 &a, const float4 &b) { a.x += b.x; a
 // again.  Measured on the predict kernel with the 8 GiB table: 133.3 -> 122.1 ms at K=356 and 275 -> 253 ms at K=1564
 // (the default policy tops out near 6.3 TB/s of HBM traffic, nt reaches 6.9).  Small tables keep the default policy:
 // they live in L2 / the Infinity Cache, which nt loads bypass (2^20 slots: 29.6 ms default, 72.6 ms nt).
-template <int VEC> __device__ __forceinline__ typename VecOf<VEC>::type nt_load(const float *p);
-template <> __device__ __forceinline__ float nt_load<1>(const float *p) { return __builtin_nontemporal_load(p); }
-template <> __device__ __forceinline__ float2 nt_load<2>(const float *p)
+// The row (h*K) mod 2^b starts at a multiple of gcd(K, 4) floats: for K that is not a multiple of 4 (K = the number of distinct
+// taxids, reference opal.py:288: any value) the 16-byte vectors of a row are only 4- or 8-byte aligned.  gfx950 global loads
+// take any dword-aligned address (unaligned access mode), so the vector types below declare 4-byte alignment and the
+// compiler still emits ONE global_load_dwordx4 / dwordx2 per lane; an aligned address costs nothing extra.
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+template <int VEC, bool NT> __device__ __forceinline__ typename VecOf<VEC>::type row_load(const float *p);
+template <> __device__ __forceinline__ float row_load<1, true>(const float *p) { return __builtin_nontemporal_load(p); }
+template <> __device__ __forceinline__ float row_load<1, false>(const float *p) { return *p; }
+template <> __device__ __forceinline__ float2 row_load<2, true>(const float *p)
 {
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    const f2 v = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(p));
+    const f2u v = __builtin_nontemporal_load(reinterpret_cast<const f2u *>(p));
     return make_float2(v.x, v.y);
 }
-template <> __device__ __forceinline__ float4 nt_load<4>(const float *p)
+template <> __device__ __forceinline__ float2 row_load<2, false>(const float *p)
 {
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p));
+    const f2u v = *reinterpret_cast<const f2u *>(p);
+    return make_float2(v.x, v.y);
+}
+template <> __device__ __forceinline__ float4 row_load<4, true>(const float *p)
+{
+    const f4u v = __builtin_nontemporal_load(reinterpret_cast<const f4u *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+template <> __device__ __forceinline__ float4 row_load<4, false>(const float *p)
+{
+    const f4u v = *reinterpret_cast<const f4u *>(p);
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
@@ -545,8 +560,7 @@ __device__ __forceinline__ void stream_rows(const float *__restrict__ tab, const
     };
     auto ld = [&](uint32_t row, uint32_t lo) -> V {
         if constexpr (WRAP) return *reinterpret_cast<const V *>(tab + (size_t)((row + lo) & mask));   // trainer: nt measured 3 % slower
-        else if constexpr (NT) return nt_load<VEC>(tab + (size_t)row + lo);
-        else return *reinterpret_cast<const V *>(tab + (size_t)row + lo);
+        else return row_load<VEC, NT>(tab + (size_t)row + lo);
     };
 #pragma unroll
     for (int u = 0; u < U; u++) {

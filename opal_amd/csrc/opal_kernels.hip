@@ -560,7 +560,9 @@ __global__ __launch_bounds__(BLOCK) void predict_kernel(Batch B, Geom G, const f
 #pragma unroll
             for (int j = 0; j < NV; j++) {
                 cls[j] = c0 + (uint32_t)(j * WAVE + lane) * VEC;
-                loff[j] = min(cls[j], Ku - VEC);  // lanes past the row's end re-read its last vector (same cache line)
+                // lanes past the row's end re-read its last vector (same cache line); when K is not a multiple of VEC the last
+                // live lane does too: its vector starts at K - VEC and overlaps its neighbour's classes (same sums, same order)
+                loff[j] = min(cls[j], Ku - VEC);
             }
             V acc[NV];
 #pragma unroll
@@ -588,10 +590,10 @@ __global__ __launch_bounds__(BLOCK) void predict_kernel(Batch B, Geom G, const f
                             else if (s < min_label) s = min_label;
                         }
                         sc[e] = s;
-                        if (best_c == 0xffffffffu || s > best) { best = s; best_c = cls[j] + e; }
+                        if (best_c == 0xffffffffu || s > best) { best = s; best_c = loff[j] + e; }
                     }
                     if (out_scores) {
-                        float *o = out_scores + frag * (uint64_t)Ku + cls[j];
+                        float *o = out_scores + frag * (uint64_t)Ku + loff[j];
 #pragma unroll
                         for (int e = 0; e < VEC; e++) o[e] = sc[e];
                     }
@@ -767,8 +769,8 @@ struct Variant {
 #define OPAL_V(VEC, NV, U) {VEC, NV, U, (const void *)&predict_kernel<VEC, NV, U, false>, (const void *)&predict_kernel<VEC, NV, U, true>, \
                            "predict_kernel<VEC=" #VEC ",NV=" #NV ",U=" #U ">"}
 const Variant kVariants[] = {
-    OPAL_V(1, 1, 8), OPAL_V(1, 2, 8), OPAL_V(1, 3, 4), OPAL_V(1, 4, 4), OPAL_V(1, 5, 2), OPAL_V(1, 6, 2), OPAL_V(1, 7, 2), OPAL_V(1, 8, 2),
-    OPAL_V(2, 1, 8), OPAL_V(2, 2, 8), OPAL_V(2, 3, 4), OPAL_V(2, 4, 4), OPAL_V(2, 5, 2), OPAL_V(2, 6, 2), OPAL_V(2, 7, 2), OPAL_V(2, 8, 2),
+    OPAL_V(1, 1, 8),   // K = 1
+    OPAL_V(2, 1, 8),   // K = 2, 3
     OPAL_V(4, 1, 8), OPAL_V(4, 2, 8), OPAL_V(4, 3, 4), OPAL_V(4, 4, 4), OPAL_V(4, 5, 2), OPAL_V(4, 6, 2), OPAL_V(4, 7, 2), OPAL_V(4, 8, 2),
 };
 
@@ -776,7 +778,9 @@ constexpr uint64_t NT_TABLE_BYTES = 4ull << 30;   // tables from this size on ar
 
 const Variant &pick_variant(int K)
 {
-    const int vec = (K % 4 == 0) ? 4 : (K % 2 == 0) ? 2 : 1;
+    // 16-byte row loads for every K >= 4 whatever K mod 4 is (dword-aligned dwordx4 loads, see row_load): with 4-byte loads
+    // for odd K the kernel ran at 77 % instead of 86 % of the HBM peak at K = 1563 against 1564 (scripts/oddk_bench.py)
+    const int vec = K >= 4 ? 4 : K >= 2 ? 2 : 1;
     int nv = (K + WAVE * vec - 1) / (WAVE * vec);
     if (nv > 8) nv = 8;  // larger K: class chunks of 64*vec*8, the fragment is re-hashed per chunk
     for (const Variant &v : kVariants)
