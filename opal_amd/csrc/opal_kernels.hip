@@ -61,11 +61,14 @@ constexpr int EF_WAVE_BYTES = 2 * SEQB + HB_EMIT * 4;   // per-wave LDS of the g
 // Reads Z[lane + (base + q_i)/4] for wave-uniform byte offsets.  M0 is written one instruction before the read that uses it
 // (the ISA asks for one wait state between an SALU write of M0 and an LDS "add-TID" instruction): the add that forms the
 // next address is that instruction, so a gather costs two scalar instructions and no vector one.
+// M0 is on the clobber lists: the compiler reserves it and merges its own M0 initialisations across code that does not
+// visibly define it.  clang warns that clobbers of reserved registers "may not be preserved" (-Winline-asm, switched off
+// in the build flags): not being preserved is what the clobber says.
 __device__ __forceinline__ uint32_t zread1(uint32_t base, uint32_t q0)
 {
     uint32_t x, t;
     asm volatile("s_add_u32 %1, %2, %3\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tds_read_addtid_b32 %0\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(x), "=&s"(t) : "s"(base), "s"(q0) : "memory", "scc");
+                 : "=&v"(x), "=&s"(t) : "s"(base), "s"(q0) : "memory", "scc", "m0");
     return x;
 }
 __device__ __forceinline__ void zread4(uint32_t base, uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3, uint32_t (&x)[4])
@@ -78,7 +81,7 @@ __device__ __forceinline__ void zread4(uint32_t base, uint32_t q0, uint32_t q1, 
                  "s_nop 0\n\tds_read_addtid_b32 %3\n\t"
                  "s_waitcnt lgkmcnt(0)"
                  : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&s"(t0), "=&s"(t1)
-                 : "s"(base), "s"(q0), "s"(q1), "s"(q2), "s"(q3) : "memory", "scc");
+                 : "s"(base), "s"(q0), "s"(q1), "s"(q2), "s"(q3) : "memory", "scc", "m0");
 }
 __device__ __forceinline__ void zread8(uint32_t base, const uint32_t (&q)[8], uint32_t (&x)[8])
 {
@@ -95,7 +98,7 @@ __device__ __forceinline__ void zread8(uint32_t base, const uint32_t (&q)[8], ui
                  "s_waitcnt lgkmcnt(0)"
                  : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]),
                    "=&s"(t0), "=&s"(t1)
-                 : "s"(base), "s"(q[0]), "s"(q[1]), "s"(q[2]), "s"(q[3]), "s"(q[4]), "s"(q[5]), "s"(q[6]), "s"(q[7]) : "memory", "scc");
+                 : "s"(base), "s"(q[0]), "s"(q[1]), "s"(q[2]), "s"(q[3]), "s"(q[4]), "s"(q[5]), "s"(q[6]), "s"(q[7]) : "memory", "scc", "m0");
 }
 // zread1 + zread8 in one batch (the canonical two-pattern step: pattern 0's one word and the first half of pattern 1's gathers)
 __device__ __forceinline__ void zread9(uint32_t base, uint32_t r, const uint32_t (&q)[8], uint32_t &xr, uint32_t (&x)[8])
@@ -114,7 +117,7 @@ __device__ __forceinline__ void zread9(uint32_t base, uint32_t r, const uint32_t
                  "s_waitcnt lgkmcnt(0)"
                  : "=&v"(xr), "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]),
                    "=&s"(t0), "=&s"(t1)
-                 : "s"(base), "s"(r), "s"(q[0]), "s"(q[1]), "s"(q[2]), "s"(q[3]), "s"(q[4]), "s"(q[5]), "s"(q[6]), "s"(q[7]) : "memory", "scc");
+                 : "s"(base), "s"(r), "s"(q[0]), "s"(q[1]), "s"(q[2]), "s"(q[3]), "s"(q[4]), "s"(q[5]), "s"(q[6]), "s"(q[7]) : "memory", "scc", "m0");
 }
 // the block's table offset from the four words that hold its letters at bits 2-3, 4-5, 6-7, 8-9 (v_and + 3 v_and_or)
 // (left to the compiler the same expression takes 5 instructions: three v_and, one v_and_or, one v_or3)
@@ -204,24 +207,32 @@ __device__ __forceinline__ void emit_fast_step(const uint32_t *__restrict__ fast
     }
 }
 
-// Stages one fragment (2-bit packed, len <= EF_MAXLEN, its dwords inside the buffer) as the per-base arrays Z_f, Z_r.
-__device__ __forceinline__ void emit_stage(const Batch &B, const Geom &G, uint64_t off, uint32_t len, uint32_t *zw, int lane)
+// A fragment's packed dwords, fetched ahead of their use: lane l (< EF_PKLEN) holds the two dwords that, funnel-shifted by
+// the fragment's offset inside its first dword, give dword l - 1 of the fragment.  The fast kernels issue these loads for the
+// NEXT fragment of a draw before they walk the current one, so that the HBM latency of a random 50-byte read (views into
+// 1.5 GB of genomes: nothing is cache-resident) is hidden behind a fragment's worth of hashing.
+struct EmitFetch { uint32_t lo, hi; };
+__device__ __forceinline__ EmitFetch emit_fetch(const Batch &B, uint64_t off, int lane)
 {
-    uint32_t *zf = zw, *zr = zw + EF_ZLEN, *pkf = zw + 2 * EF_ZLEN, *pkr = pkf + EF_PKLEN;
     const uint32_t *__restrict__ R32 = reinterpret_cast<const uint32_t *>(B.reads);
     const uint64_t nd = B.reads_bytes >> 2;
     const uint64_t a0 = off >> 4;
+    EmitFetch f{0u, 0u};
+    if (lane > 0 && lane < EF_PKLEN) {
+        f.lo = R32[min(a0 + (uint64_t)lane - 1u, nd - 1)];
+        f.hi = R32[min(a0 + (uint64_t)lane, nd - 1)];
+    }
+    return f;
+}
+
+// Stages one fragment (2-bit packed, len <= EF_MAXLEN, its dwords inside the buffer, fetched by emit_fetch) as the per-base arrays Z_f, Z_r.
+__device__ __forceinline__ void emit_stage(const EmitFetch &pf, const Geom &G, uint64_t off, uint32_t len, uint32_t *zw, int lane)
+{
+    uint32_t *zf = zw, *zr = zw + EF_ZLEN, *pkf = zw + 2 * EF_ZLEN, *pkr = pkf + EF_PKLEN;
     const uint32_t sh = (uint32_t)(off & 15u) * 2u;
     const uint32_t S = G.reverse ? 2u : 1u;
     // the fragment's bases as packed dwords behind one zero dword: base 0 of the fragment at bit 0 of pkf[1]
-    if (lane < EF_PKLEN) {
-        uint32_t v = 0;
-        if (lane > 0) {
-            const uint32_t lo = R32[min(a0 + (uint64_t)lane - 1u, nd - 1)], hi = R32[min(a0 + (uint64_t)lane, nd - 1)];
-            v = __builtin_amdgcn_alignbit(hi, lo, sh);
-        }
-        pkf[lane] = v;
-    }
+    if (lane < EF_PKLEN) pkf[lane] = lane > 0 ? __builtin_amdgcn_alignbit(pf.hi, pf.lo, sh) : 0u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (S == 2 && lane < EF_PKLEN) {
@@ -245,12 +256,12 @@ __device__ __forceinline__ void emit_stage(const Batch &B, const Geom &G, uint64
     // same in every iteration and all LDS addresses are one per-lane base + immediates: one VALU instruction per 64 entries.
     {
         const uint32_t bo = 2u * (uint32_t)lane + 30u, b = bo & 31u;
-        const uint32_t *pf = pkf + (bo >> 5), *pr = pkr + (bo >> 5);
+        const uint32_t *pff = pkf + (bo >> 5), *pr = pkr + (bo >> 5);
         uint32_t *zfl = zf + lane, *zrl = zr + lane;
 #pragma unroll
         for (int it = 0; it < EF_MAXLEN / WAVE + 1; it++) {
             if ((uint32_t)(it * WAVE) > len) break;
-            zfl[it * WAVE] = __builtin_amdgcn_alignbit(pf[4 * it + 1], pf[4 * it], b);
+            zfl[it * WAVE] = __builtin_amdgcn_alignbit(pff[4 * it + 1], pff[4 * it], b);
             if (S == 2) zrl[it * WAVE] = __builtin_amdgcn_alignbit(pr[4 * it + 1], pr[4 * it], b);
         }
     }
@@ -259,10 +270,10 @@ __device__ __forceinline__ void emit_stage(const Batch &B, const Geom &G, uint64
 }
 
 // Hashes fragment `frag` (2-bit packed, k <= len <= EF_MAXLEN, its dwords inside the buffer) into dst[0 .. S*W*P).
-__device__ __forceinline__ void emit_fast(const Batch &B, const Geom &G, uint64_t off, uint32_t len, uint32_t mask, uint32_t *zw,
+__device__ __forceinline__ void emit_fast(const EmitFetch &pf, const Geom &G, uint64_t off, uint32_t len, uint32_t mask, uint32_t *zw,
                                           const uint32_t *tab, int lane, uint32_t *__restrict__ dst)
 {
-    emit_stage(B, G, off, len, zw, lane);
+    emit_stage(pf, G, off, len, zw, lane);
     uint32_t *zf = zw, *zr = zw + EF_ZLEN;
     const uint32_t S = G.reverse ? 2u : 1u;
     const uint32_t W = len - (uint32_t)G.k + 1u, U = S * W;
@@ -282,8 +293,10 @@ __device__ __forceinline__ void emit_fast(const Batch &B, const Geom &G, uint64_
 // the buffer (locate_fragment's rule for the fragment itself; fragments in the buffer's last, partial dword go the generic way).
 __device__ __forceinline__ bool emit_fast_takes(const Batch &B, const Geom &G, uint32_t lw, uint64_t off)
 {
-    return !(lw & OPAL_RAW_FLAG) && lw >= (uint32_t)G.k && lw <= (uint32_t)EF_MAXLEN && ((off + lw + 3) >> 2) <= B.reads_bytes &&
-           ((off + lw + 15) >> 4) <= (B.reads_bytes >> 2);
+    // (off <= 4 * reads_bytes first: an offset near 2^64 must not wrap the sums below and slip through; locate_fragment
+    // rejects it, so such a fragment goes to the generic kernel and is reported by opal_sync)
+    return !(lw & OPAL_RAW_FLAG) && lw >= (uint32_t)G.k && lw <= (uint32_t)EF_MAXLEN && off <= (B.reads_bytes << 2) &&
+           ((off + lw + 3) >> 2) <= B.reads_bytes && ((off + lw + 15) >> 4) <= (B.reads_bytes >> 2);
 }
 __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l)
 {
@@ -388,11 +401,17 @@ __global__ __launch_bounds__(BLOCK) void emit_canon2_kernel(Batch B, Geom G, uin
             mine_left = fits && !take;
         }
         left += (uint32_t)__popcll(__ballot(mine_left));   // wave-uniform
-        for (uint64_t todo = __ballot(take); todo; todo &= todo - 1) {
+        uint64_t todo = __ballot(take);
+        EmitFetch nxt{0u, 0u};
+        if (todo) nxt = emit_fetch(B, readlane64(off, __builtin_ctzll(todo)), lane);
+        while (todo) {
             const int i = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const EmitFetch cur = nxt;
+            if (todo) nxt = emit_fetch(B, readlane64(off, __builtin_ctzll(todo)), lane);   // in flight while fragment i is hashed
             uint32_t *dst = out_idx + readlane64(o0, i);
             const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)lw, i);
-            emit_stage(B, G, readlane64(off, i), len, zw, lane);
+            emit_stage(cur, G, readlane64(off, i), len, zw, lane);
             const uint32_t W = len - (uint32_t)G.k + 1u, U = S * W;
             for (uint32_t u0 = 0; u0 < U; u0 += WAVE) {
                 const uint32_t u = u0 + (uint32_t)lane;
@@ -447,9 +466,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FAST ? 7 
         }
         if (FAST) left += (uint32_t)__popcll(__ballot(mine_left));   // wave-uniform
         if constexpr (FAST) {
-            for (uint64_t todo = __ballot(take); todo; todo &= todo - 1) {
+            uint64_t todo = __ballot(take);
+            EmitFetch nxt{0u, 0u};
+            if (todo) nxt = emit_fetch(B, readlane64(off, __builtin_ctzll(todo)), lane);
+            while (todo) {
                 const int i = __builtin_ctzll(todo);
-                emit_fast(B, G, readlane64(off, i), (uint32_t)__builtin_amdgcn_readlane((int)lw, i), mask,
+                todo &= todo - 1;
+                const EmitFetch cur = nxt;
+                if (todo) nxt = emit_fetch(B, readlane64(off, __builtin_ctzll(todo)), lane);   // in flight while fragment i is hashed
+                emit_fast(cur, G, readlane64(off, i), (uint32_t)__builtin_amdgcn_readlane((int)lw, i), mask,
                           reinterpret_cast<uint32_t *>(s_wave[wv]), s_tab, lane, out_idx + readlane64(o0, i));
             }
         } else {
