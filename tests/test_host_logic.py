@@ -410,3 +410,16 @@ def test_fasta_pieces_preserve_the_reference_readers_records(tmp_path, oracle):
                 for r in range(3):
                     got3 += oracle.fasta_read(per_rank[r][rnd].tobytes())
             assert [s for _, s in got3] == [s for _, s in want], (ti, chunk, "3 ranks")
+
+
+def test_traffic_json_follows_the_committed_profiles():
+    """bench.py quotes roofline.traffic from profiles/traffic.json; the file is generated from the profile summaries
+    (scripts/make_traffic_json.py) and must be regenerated whenever a profile is refreshed."""
+    import importlib.util
+    import json
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_traffic_json", os.path.join(ROOT, "scripts", "make_traffic_json.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+        assert json.load(f) == mod.build()
