@@ -13,6 +13,8 @@ import itertools
 import os
 import sys
 
+import numpy as np
+
 from .engine import Engine, PackedReads, check_geometry, parse_patterns
 from .fasta_functions import fasta_reader
 
@@ -58,6 +60,16 @@ def vw_text_lines(engine: Engine, seqs, reverse, labels=None, chunk=4096):
         names, off = engine.feature_names(batch, reverse)
         names = names.cpu().numpy()
         off = off.cpu().numpy()
+        if P <= 10:
+            # one-digit pattern index: every feature is t + 2 bytes "<t chars><digit> ", laid out for the whole chunk at once
+            # (every fragment's feature count is a multiple of P, so the pattern index is the global feature index mod P)
+            cells = np.empty((names.shape[0], t + 2), dtype=np.uint8)
+            cells[:, :t] = names
+            cells[:, t] = ord("0") + np.arange(names.shape[0]) % P
+            cells[:, t + 1] = ord(" ")
+            for i in range(len(part)):
+                out.append(("%s | " % next(labels)).encode() + cells[off[i]:off[i + 1]].tobytes()[:-1] + b"\n")
+            continue
         for i in range(len(part)):
             rows = names[off[i]:off[i + 1]]
             feats = [rows[f].tobytes() + suffix[f % P] for f in range(rows.shape[0])]

@@ -10,7 +10,9 @@ The reference modules exercised (file:line in /root/reference):
   util/ldpc.py:10-37,66-97        ldpc(), write_out(), ldpc_write()      -> patterns_*.txt
   util/drawfrag.py:15-49          main_not_commandline() via main(argv)   -> drawfrag_*.json
   util/fasta_functions.py:9-54    fasta_reader, reverse_complement, get_all_substrings
-  util/fasta2skm.py:19-44,47-84,120-141  update_dictionary, main_generator, gen_features -> skm_*.json
+  util/fasta2skm.py:19-44,47-84,120-141  update_dictionary, main_generator, gen_features -> skm_*.json, skm_corpus.json
+                                  (skm_corpus.json: digests of the lines and of the hashed indices for ~2100 fragments per
+                                  geometry; the fragments come from tests/golden/corpus_gen.py, which the tests share)
   CPython `random` (what drawfrag.py:24,38 and opal.py:363 call)          -> pyrandom.json
   opal.py:52-88,111-138           unique_lines, extract_column_two, vw_class_to_taxid, evaluate_predictions
                                                                           -> opal_helpers.json
@@ -230,6 +232,41 @@ def gen_skm():
         json.dump(cases, f)
 
 
+# ---------------------------------------------------------------- (iii b) hash-only corpus: thousands of fragments, digests only
+def gen_skm_corpus():
+    """~2100 deterministic fragments (tests/golden/corpus_gen.py: lengths 0..600, alphabets ACGT / ACGTacgtNn / IUPAC) per
+    geometry P in {2, 5, 9} and -r on/off through the reference's main_generator (util/fasta2skm.py:47-84); stored per case:
+    SHA-256 of the concatenated VW text lines, SHA-256 of the little-endian u32 stream of murmurhash3_32(name) & (2^b - 1)
+    for b = 32 and 31 (sklearn's MurmurHash3: independent of the build), SHA-256 of the per-line feature counts."""
+    import hashlib
+    import corpus_gen
+    per_alphabet = 700
+    cases = []
+    for m in (1, 4, 8):
+        pat = os.path.join(HERE, "patterns_k64_t16_m%d_s7.txt" % m)
+        for rev in (False, True):
+            name = "corpus_m%d_r%d" % (m, rev)
+            seqs = corpus_gen.fragments(name, per_alphabet)
+            lines, _ = skm_lines(corpus_gen.fasta_text(seqs), pat, 64, rev)
+            assert len(lines) == len(seqs)
+            text = hashlib.sha256("".join(lines).encode("latin-1"))
+            counts, hs = [], []
+            for ln in lines:
+                names = ln.rstrip("\n").split("|", 1)[1].split()
+                counts.append(len(names))
+                hs.extend(murmurhash3_32(nm.encode("latin-1"), seed=0, positive=True) for nm in names)
+            h = np.array(hs, dtype=np.uint32)
+            cases.append({"name": name, "pattern": os.path.basename(pat), "k": 64, "reverse": rev, "per_alphabet": per_alphabet,
+                          "fragments": len(seqs), "features": int(h.size), "text_bytes": sum(len(ln) for ln in lines),
+                          "text_sha256": text.hexdigest(),
+                          "counts_sha256": hashlib.sha256(np.array(counts, dtype="<u8").tobytes()).hexdigest(),
+                          "idx32_sha256": hashlib.sha256(h.astype("<u4").tobytes()).hexdigest(),
+                          "idx31_sha256": hashlib.sha256((h & np.uint32(0x7FFFFFFF)).astype("<u4").tobytes()).hexdigest()})
+            print(name, len(seqs), "fragments", h.size, "features", flush=True)
+    with open(os.path.join(HERE, "skm_corpus.json"), "w") as f:
+        json.dump(cases, f, indent=0)
+
+
 # ---------------------------------------------------------------- (v) dico evolution
 def gen_dico():
     rng = random.Random(3)
@@ -384,10 +421,15 @@ def gen_train_stream():
 
 
 if __name__ == "__main__":
+    sys.path.insert(0, HERE)
+    if "--only-corpus" in sys.argv:
+        gen_skm_corpus()
+        sys.exit(0)
     gen_opal_helpers()
     gen_train_stream()
     if "--only-new" in sys.argv:
         sys.exit(0)
+    gen_skm_corpus()
     gen_patterns()
     gen_drawfrag()
     gen_pyrandom()

@@ -90,6 +90,41 @@ def test_vw_text_lines_rebuilt_from_gpu_names(amd, eng, oracle, golden_dir):
         assert [l.decode("latin-1") for l in lines] == c["lines"], c["name"]
 
 
+def test_corpus_digests_direct_from_the_reference(amd, eng, golden_dir):
+    """GPU output against the REFERENCE's output at fuzz scale, with no oracle in between: ~2100 fragments per geometry
+    (P in {2, 5, 9}, -r on/off; lengths 0..600 so both emit kernels run; ACGT, mixed case + N, IUPAC) went through the
+    reference's main_generator (tests/golden/make_golden.py gen_skm_corpus); the digests of its VW text and of the
+    sklearn-hashed index stream are rebuilt here from opal_feature_names / opal_features."""
+    import hashlib
+    import sys
+    from opal_amd import fasta2skm
+    sys.path.insert(0, golden_dir)
+    import corpus_gen
+    eng.set_vw_options(hash_all=True)          # the golden hashes are pure murmur (sklearn); no name of the corpus is all digits
+    for c in _load(golden_dir, "skm_corpus.json"):
+        pos = _patterns(amd, golden_dir, c["pattern"], c["k"])
+        eng.set_patterns(pos, c["k"])
+        seqs = corpus_gen.fragments(c["name"], c["per_alphabet"])
+        assert len(seqs) == c["fragments"]
+        batch = eng.upload(amd.PackedReads.from_sequences(seqs))
+        idx, off = eng.features(batch, c["reverse"], 32)
+        idx, off = _u32(idx), off.cpu().numpy()
+        assert idx.size == c["features"], c["name"]
+        assert hashlib.sha256(np.diff(off).astype("<u8").tobytes()).hexdigest() == c["counts_sha256"], c["name"]
+        assert hashlib.sha256(idx.astype("<u4").tobytes()).hexdigest() == c["idx32_sha256"], c["name"]
+        idx31, _ = eng.features(batch, c["reverse"], 31)
+        assert hashlib.sha256(_u32(idx31).astype("<u4").tobytes()).hexdigest() == c["idx31_sha256"], c["name"]
+        text = hashlib.sha256()
+        nbytes = 0
+        for line in fasta2skm.vw_text_lines(eng, seqs, c["reverse"], labels=None, chunk=512):
+            text.update(line)
+            nbytes += len(line)
+        assert nbytes == c["text_bytes"], c["name"]
+        assert text.hexdigest() == c["text_sha256"], c["name"]
+    eng.set_vw_options()
+    eng.sync()
+
+
 # ------------------------------------------------------------------------------ fused predict vs oracle
 @pytest.mark.parametrize("K,bits", [(10, 12), (7, 16), (1, 10), (64, 14), (356, 12), (356, 20), (1564, 20), (1563, 18),
                                     (2050, 18), (4100, 16), (130, 31 - 9)])

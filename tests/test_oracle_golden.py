@@ -166,3 +166,27 @@ def test_scoring_matches_numpy_restatement(oracle, golden_dir):
         cls2, sc2, _ = oracle.predict(seqs, c["k"], pos, True, w, K, bits, clip=True, min_label=-0.3, max_label=0.2)
         assert np.array_equal(sc2, np.clip(sc, -0.3, 0.2))
         assert cls2.tolist() == (np.argmax(sc2, axis=1) + 1).tolist()
+
+
+# ---------------------------------------------------------------- hash-only corpus (digests of the reference's output)
+def test_corpus_digests(oracle, golden_dir):
+    """~2100 fragments per geometry (lengths 0..600, ACGT / mixed case + N / IUPAC; tests/golden/corpus_gen.py) went through the
+    reference's main_generator; skm_corpus.json keeps SHA-256 digests of its lines and of the sklearn-hashed indices."""
+    import hashlib
+    import sys
+    sys.path.insert(0, golden_dir)
+    import corpus_gen
+    for c in _load(golden_dir, "skm_corpus.json"):
+        pos = _patterns(oracle, golden_dir, c["pattern"], c["k"])
+        seqs = corpus_gen.fragments(c["name"], c["per_alphabet"])
+        assert len(seqs) == c["fragments"]
+        idx, off = oracle.features_batch(seqs, c["k"], pos, c["reverse"], 32, hash_all=True, nthreads=4)
+        assert idx.size == c["features"], c["name"]
+        assert hashlib.sha256(np.diff(off).astype("<u8").tobytes()).hexdigest() == c["counts_sha256"], c["name"]
+        assert hashlib.sha256(idx.astype("<u4").tobytes()).hexdigest() == c["idx32_sha256"], c["name"]
+        assert hashlib.sha256((idx & np.uint32(0x7FFFFFFF)).astype("<u4").tobytes()).hexdigest() == c["idx31_sha256"], c["name"]
+        if c["features"] < 3_000_000:        # the text of the larger cases (up to 160 MB) is checked on the GPU side only
+            text = hashlib.sha256()
+            for s in seqs:
+                text.update(oracle.vw_line(s, c["k"], pos, c["reverse"], "1"))
+            assert text.hexdigest() == c["text_sha256"], c["name"]
