@@ -316,7 +316,7 @@ __global__ __launch_bounds__(BLOCK) void ing_scan_local_kernel(const Sum *__rest
 //      [3] raw records, [4] a record is longer than 2^31-1, [5] the last record is empty (dropped), [6] raw area overflow,
 //      [7] a byte outside ACGT in front of the first header (makes record 0 raw when the text has no header at all),
 //      [8] a look-back gave up waiting (never seen; the exit every spinning wave reaches)
-enum { F_H = 0, F_T, F_CURSOR, F_NRAW, F_TOOLONG, F_DROPPED, F_OVERFLOW, F_PREBAD, F_STALL, F_WORDS = 16 };
+enum { F_H = 0, F_T, F_CURSOR, F_NRAW, F_TOOLONG, F_DROPPED, F_OVERFLOW, F_PREBAD, F_STALL, F_TICKET, F_WORDS = 16 };
 constexpr int SC_ITEMS = 2;
 constexpr int SC_WAVES = 4;
 constexpr int SC_BLOCK = SC_WAVES * WAVE;
@@ -417,9 +417,9 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, int l)
 
 // Decoupled look-back of one wave: lane i looks at tile t-1-i (then 64 further back, ...).  The nearest tile whose end
 // state is published gives the start; the summaries of the tiles between it and t are applied on top, in text order.
-// Tiles are taken in index order by blocks that are all resident (or dispatched in index order), so the tile this
-// wave waits for is always being worked on; should that ever fail, the wave gives up after LOOKBACK_SPINS polls and the
-// call fails with OPAL_EHIP instead of hanging.
+// Tiles are tickets drawn in the order blocks start (ing_fused_kernel), so the tile this wave waits for is always being
+// worked on by a resident block; as a last line of defence the wave gives up after LOOKBACK_SPINS polls and the call fails
+// with OPAL_EHIP instead of hanging.
 constexpr uint32_t LOOKBACK_SPINS = 1u << 20;
 __device__ __forceinline__ Pre look_back(const Desc *desc, uint64_t t, int lane, uint64_t *fin)
 {
@@ -480,10 +480,16 @@ __global__ __launch_bounds__(BLOCK) void ing_fused_kernel(const uint8_t *__restr
     __shared__ Sum s_w[WPB];
     __shared__ uint32_t s_bits[ING_LDS_WORDS];
     __shared__ Pre s_tp;
+    __shared__ uint64_t s_ticket;
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
     {
-        const uint64_t t = blockIdx.x;
+        // The tile is a ticket drawn when the block starts, not blockIdx.x: HIP does not promise that blocks are dispatched
+        // in index order, and a look-back may only wait for tiles whose blocks are already running.  Tickets are handed out
+        // in the order blocks start, so every tile below this one belongs to a block that is resident or done.
+        if (threadIdx.x == 0) s_ticket = atomicAdd((unsigned long long *)&fin[F_TICKET], 1ull);
         for (int i = threadIdx.x; i < ING_LDS_WORDS; i += BLOCK) s_bits[i] = 0;   // ordered by the scan's barriers
+        __syncthreads();
+        const uint64_t t = s_ticket;
         const uint64_t base = t * ING_TILE + (uint64_t)threadIdx.x * ING_THREAD_BYTES;
         uint32_t x[CPT][4];
         Masks m[CPT];

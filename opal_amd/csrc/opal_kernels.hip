@@ -897,12 +897,15 @@ extern "C" int opal_ctx_destroy(opal_ctx *ctx)
 extern "C" int opal_sync(opal_ctx *ctx)
 {
     if (!ctx) return opal::fail(nullptr, OPAL_EINVAL, "opal_sync: null ctx");
-    OPAL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    // fragments of opal_features / opal_feature_names calls that reached outside their d_reads (queue word 3)
+    // fragments of opal_features / opal_feature_names calls that reached outside their d_reads (queue word Q_BAD): read and
+    // cleared on the ctx's own stream, so that a ctx on a stream of its own never serialises against the null stream
     unsigned long long bad = 0;
-    OPAL_HIP_CHECK(ctx, hipMemcpy(&bad, ctx->d_queue + Q_BAD, sizeof(bad), hipMemcpyDeviceToHost));
+    OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    OPAL_HIP_CHECK(ctx, hipMemcpyAsync(&bad, ctx->d_queue + Q_BAD, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
+    OPAL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (bad) {
-        OPAL_HIP_CHECK(ctx, hipMemset(ctx->d_queue + Q_BAD, 0, sizeof(bad)));
+        OPAL_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_queue + Q_BAD, 0, sizeof(bad), ctx->stream));
+        OPAL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         return opal::fail(ctx, OPAL_EINVAL, std::to_string(bad) + " fragment(s) of the emit calls since the last opal_sync reach outside d_reads "
                                             "(offset + length beyond reads_bytes): their features were written as 0xffffffff / NUL names");
     }
