@@ -542,24 +542,86 @@ template <> __device__ __forceinline__ float4 row_load<4, false>(const float *p)
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
+// Does the row that starts at slot `row` come within 3 slots of the table's end or pass it (row + K + 3 > 2^b)?  Wave-uniform.
+// Rows that do not are "contiguous": every 16-byte vector of theirs, the last, partial one included, lies inside the table,
+// and row + class never overflows 32 bits.
+struct RowCross {
+    uint32_t thr;   // 2^b - K - 3
+    bool all;       // K + 3 > 2^b (toy tables of the tests): every row does
+    __device__ __forceinline__ RowCross(uint32_t K, uint32_t mask) : thr((mask - K - 2u) & mask), all((uint64_t)K + 3ull > (uint64_t)mask + 1ull) {}
+    __device__ __forceinline__ bool operator()(uint32_t row) const { return all || row > thr; }
+};
+
+// ---- vectors of the trainers' tables.  A row (h*K) mod 2^b starts at any slot when K is not a multiple of 4, so the 16-byte
+// vectors of a row are only dword aligned (loads and stores through f4u / f2u: still one dwordx4 / dwordx2 instruction).
+template <int VEC> __device__ __forceinline__ void vloadu(const float *p, float (&o)[VEC])
+{
+    if constexpr (VEC == 4) { const f4u v = *reinterpret_cast<const f4u *>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    else if constexpr (VEC == 2) { const f2u v = *reinterpret_cast<const f2u *>(p); o[0] = v.x; o[1] = v.y; }
+    else o[0] = *p;
+}
+template <int VEC> __device__ __forceinline__ void vstoreu(float *p, const float (&o)[VEC])
+{
+    if constexpr (VEC == 4) { f4u v; v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3]; *reinterpret_cast<f4u *>(p) = v; }
+    else if constexpr (VEC == 2) { f2u v; v.x = o[0]; v.y = o[1]; *reinterpret_cast<f2u *>(p) = v; }
+    else *p = o[0];
+}
+// The VEC slots of row `row` from class c on, for a lane that has work (`on`; lanes without read slot 0, an always-cached
+// line, so that the load itself is unconditional).  `crossing` is wave-uniform (RowCross): the row reaches the table's end
+// and every slot is wrapped on its own; otherwise the row is contiguous and ONE vector load serves the lane -- when K is not
+// a multiple of VEC the row's last vector reaches up to VEC - 1 slots past the row (still inside the table); what it finds
+// there belongs to no class of this row and the callers mask it.
+// MASKED (K a multiple of VEC, so a vector never straddles the table's end): the lane wraps its own address, no case split.
+template <int VEC, bool MASKED = false>
+__device__ __forceinline__ void row_vload(const float *tab, uint32_t row, uint32_t c, uint32_t K, uint32_t mask, bool crossing, bool on,
+                                          float (&o)[VEC])
+{
+    if constexpr (MASKED) {
+        vloadu<VEC>(tab + (on ? (size_t)((row + c) & mask) : (size_t)0), o);
+    } else if (!crossing) {
+        vloadu<VEC>(tab + (size_t)(on ? row + c : 0u), o);      // 32-bit sum: cannot overflow for a contiguous row
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; e++) o[e] = tab[on ? (size_t)((row + min(c + (uint32_t)e, K - 1u)) & mask) : (size_t)0];
+    }
+}
+// Stores the lane's slots of the row that belong to a class (c + e < K): one vector store when all VEC do and the row is
+// contiguous, slot by slot otherwise (the row's last, partial vector; rows that pass the table's end).
+template <int VEC, bool MASKED = false>
+__device__ __forceinline__ void row_vstore(float *tab, uint32_t row, uint32_t c, uint32_t K, uint32_t mask, bool crossing, const float (&o)[VEC])
+{
+    if constexpr (MASKED) {
+        vstoreu<VEC>(tab + (size_t)((row + c) & mask), o);
+    } else if (!crossing && c + (uint32_t)VEC <= K) {
+        vstoreu<VEC>(tab + (size_t)(row + c), o);
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; e++)
+            if (c + (uint32_t)e < K) tab[(size_t)((row + c + (uint32_t)e) & mask)] = o[e];
+    }
+}
+
 // Streams rows hb[0..nf) of the padded weight table into acc.  hb[nf .. nf+U) must be readable (dummy rows:
 // they are loaded and never consumed).  loff[j] = this lane's float offset inside a row for vector j (already
 // clamped into the row, so every load is unconditional).
-template <int VEC, int NV, int U, bool WRAP = false, bool NT = false>
+template <int VEC, int NV, int U, int WRAP = 0, bool NT = false>
 __device__ __forceinline__ void stream_rows(const float *__restrict__ tab, const uint32_t *hb, uint32_t nf, uint32_t K,
                                             uint32_t mask, const uint32_t (&loff)[NV],
                                             typename VecOf<VEC>::type (&acc)[NV])
 {
     using V = typename VecOf<VEC>::type;
     V r[U][NV];
-    // WRAP=false: the table is padded with a mirror of its head, rows are contiguous (predict).
-    // WRAP=true : canonical slots only, every lane wraps its own address (trainer: the mirror may be stale).
+    // WRAP = 0: the table is padded with a mirror of its head, rows run on into it (predict).
+    // WRAP = 1: canonical slots only, every lane wraps its own address (trainers, K a multiple of VEC: the mirror may be stale).
+    // WRAP = 2: every row of hb is contiguous (RowCross says so for all of them: the trainers check a flush before they call):
+    //           no wrap, and row + lo is a 32-bit sum formed per load (no 64-bit address pair held per vector).
     auto row_of = [&](uint32_t f) -> uint32_t {
         const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)hb[f]);
         return (idx * K) & mask;  // (h*K) mod 2^b, b <= 32: low 32 bits suffice
     };
     auto ld = [&](uint32_t row, uint32_t lo) -> V {
-        if constexpr (WRAP) return *reinterpret_cast<const V *>(tab + (size_t)((row + lo) & mask));   // trainer: nt measured 3 % slower
+        if constexpr (WRAP == 1) return row_load<VEC, NT>(tab + (size_t)((row + lo) & mask));
+        else if constexpr (WRAP == 2) return row_load<VEC, NT>(tab + (size_t)(row + lo));   // trainer: nt measured 3 % slower
         else return row_load<VEC, NT>(tab + (size_t)row + lo);
     };
 #pragma unroll
@@ -588,6 +650,41 @@ __device__ __forceinline__ void stream_rows(const float *__restrict__ tab, const
             for (int j = 0; j < NV; j++) vadd(acc[j], r[u][j]);
         }
     }
+}
+
+// The trainers' sweep 1 over a flush that holds a row which passes the table's end (rare on real tables, the rule on the
+// tiny tables of the tests): row by row, every slot wrapped on its own, same order of additions per class as stream_rows.
+// cls[j] = first class of the lane's vector j (classes >= K re-read the row's last slot and are never used).
+template <int VEC, int NV>
+__device__ __forceinline__ void stream_rows_wrapped(const float *__restrict__ tab, const uint32_t *hb, uint32_t nf, uint32_t K, uint32_t mask,
+                                                    const uint32_t (&cls)[NV], typename VecOf<VEC>::type (&acc)[NV])
+{
+    float a[NV][VEC];
+#pragma unroll
+    for (int j = 0; j < NV; j++)
+#pragma unroll
+        for (int e = 0; e < VEC; e++) a[j][e] = vget<VEC>(acc[j], e);
+    for (uint32_t f = 0; f < nf; f++) {
+        const uint32_t row = ((uint32_t)__builtin_amdgcn_readfirstlane((int)hb[f]) * K) & mask;
+#pragma unroll
+        for (int j = 0; j < NV; j++)
+#pragma unroll
+            for (int e = 0; e < VEC; e++) a[j][e] += tab[(size_t)((row + min(cls[j] + (uint32_t)e, K - 1u)) & mask)];
+    }
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        if constexpr (VEC == 4) acc[j] = make_float4(a[j][0], a[j][1], a[j][2], a[j][3]);
+        else if constexpr (VEC == 2) acc[j] = make_float2(a[j][0], a[j][1]);
+        else acc[j] = a[j][0];
+    }
+}
+// true when one of the rows hb[0..nf) passes the table's end (wave-uniform result)
+__device__ __forceinline__ bool any_row_crosses(const uint32_t *hb, uint32_t nf, uint32_t K, uint32_t mask, int lane)
+{
+    const RowCross crosses(K, mask);
+    bool x = false;
+    for (uint32_t i = lane; i < nf; i += WAVE) x = x || crosses((hb[i] * K) & mask);
+    return __ballot(x) != 0ull;
 }
 
 }  // namespace

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <type_traits>
 
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -35,20 +36,6 @@
 
 namespace {
 
-template <int VEC>
-__device__ __forceinline__ void vload(const float *p, float (&o)[VEC])
-{
-    if constexpr (VEC == 4) { const float4 v = *reinterpret_cast<const float4 *>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
-    else if constexpr (VEC == 2) { const float2 v = *reinterpret_cast<const float2 *>(p); o[0] = v.x; o[1] = v.y; }
-    else o[0] = *p;
-}
-template <int VEC>
-__device__ __forceinline__ void vstore(float *p, const float (&o)[VEC])
-{
-    if constexpr (VEC == 4) *reinterpret_cast<float4 *>(p) = make_float4(o[0], o[1], o[2], o[3]);
-    else if constexpr (VEC == 2) *reinterpret_cast<float2 *>(p) = make_float2(o[0], o[1]);
-    else *p = o[0];
-}
 __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 
 struct DArgs {
@@ -70,8 +57,11 @@ __device__ __forceinline__ float step_w(float wold, float d, bool reg, float dec
 // One wave per example of the group.  Writes, per example e: upd[e][K], gsq[e][K], sfac[e] = eta / sqrt(#features), the
 // row start of every k-mer feature into keys[] (value = e) at the example's place in the group's (example, feature)
 // order, and the progressive prediction.  Reads w and G, writes neither.
-template <int VEC, int NV, int U>
-__global__ __launch_bounds__(BLOCK) void dtrain_score_kernel(Batch B, Geom G, const float *__restrict__ w, const float *__restrict__ g2,
+// AL: K is a multiple of VEC (a vector never straddles the table's end: every lane wraps its own address, as before round 3);
+// otherwise rows are split into contiguous ones (vectors on unwrapped, dword-aligned addresses) and the rare ones that reach
+// the table's end (slot by slot), see RowCross.
+template <int VEC, int NV, int U, bool AL>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(NV >= 8 ? 2 : 1))) void dtrain_score_kernel(Batch B, Geom G, const float *__restrict__ w, const float *__restrict__ g2,
                                                               uint32_t mask, int K, uint32_t const_idx,
                                                               const int32_t *__restrict__ labels, DArgs ta, uint64_t e0, uint32_t gn,
                                                               const uint64_t *__restrict__ foff, float *__restrict__ upd_out,
@@ -102,7 +92,7 @@ __global__ __launch_bounds__(BLOCK) void dtrain_score_kernel(Batch B, Geom G, co
 #pragma unroll
             for (int j = 0; j < NV; j++) {
                 cls[j] = c0 + (uint32_t)(j * WAVE + lane) * VEC;
-                loff[j] = min(cls[j], Ku - VEC);
+                loff[j] = min(cls[j], (Ku - 1u) & ~(uint32_t)(VEC - 1));   // lanes past the row re-read its last vector (which may be partial)
             }
             V acc[NV];
 #pragma unroll
@@ -118,7 +108,11 @@ __global__ __launch_bounds__(BLOCK) void dtrain_score_kernel(Batch B, Geom G, co
                         if (at < nfe) { keys[kbase + at] = (hb[i] * Ku) & mask; vals[kbase + at] = (uint32_t)e; }
                     }
                 }
-                stream_rows<VEC, NV, U, true>(w, hb, cnt, Ku, mask, loff, acc);
+                // contiguous rows: the predict kernel's pipeline, unwrapped addresses (a vector may reach up to VEC - 1 slots past its
+                // row: masked below); a flush that holds a row which passes the table's end goes slot by slot
+                if constexpr (AL) stream_rows<VEC, NV, U, 1, false>(w, hb, cnt, Ku, mask, loff, acc);
+                else if (!any_row_crosses(hb, cnt, Ku, mask, lane)) stream_rows<VEC, NV, U, 2, false>(w, hb, cnt, Ku, mask, loff, acc);
+                else stream_rows_wrapped<VEC, NV>(w, hb, cnt, Ku, mask, cls, acc);
                 nfeat += cnt;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -140,9 +134,9 @@ __global__ __launch_bounds__(BLOCK) void dtrain_score_kernel(Batch B, Geom G, co
                     else if (p > ta.max_label) p = ta.max_label;
                     else if (p < ta.min_label) p = ta.min_label;
                     const uint32_t c = cls[j] + x;
-                    if (cls[j] < Ku && (best_c == 0xffffffffu || p > best)) { best = p; best_c = c; }
+                    if (c < Ku && (best_c == 0xffffffffu || p > best)) { best = p; best_c = c; }
                     const float y = (c == label) ? 1.0f : -1.0f;
-                    err[j][x] = y - p;
+                    err[j][x] = c < Ku ? y - p : 0.0f;         // slots past the row (K not a multiple of VEC) belong to no class
                     gsq[j][x] = 4.0f * err[j][x] * err[j][x];
                     ppu[j][x] = 0.0f;
                     any = any || (err[j][x] != 0.0f);
@@ -153,6 +147,27 @@ __global__ __launch_bounds__(BLOCK) void dtrain_score_kernel(Batch B, Geom G, co
             // ppu: a read-only sweep over the accumulator rows, 4 rows in flight, loads unconditional (idle lanes read slot 0)
             walk_fragment(B, G, frag, mask, true, const_idx, s_seq[wv], hb, s_tab, lane, [&](uint32_t cnt) {
                 constexpr int U2 = (NV <= 2) ? 4 : (NV == 4 ? 2 : 1);
+                if (!AL && any_row_crosses(hb, cnt, Ku, mask, lane)) {
+                    // a row of this flush passes the table's end (rare on real tables): the whole flush slot by slot, a vector at a time
+                    for (uint32_t f = 0; f < cnt; f++) {
+                        const uint32_t row = ((uint32_t)__builtin_amdgcn_readfirstlane((int)hb[f]) * Ku) & mask;
+#pragma unroll
+                        for (int j = 0; j < NV; j++) {
+                            float gv[VEC];
+                            row_vload<VEC>(g2, row, cls[j], Ku, mask, true, act[j], gv);
+#pragma unroll
+                            for (int x = 0; x < VEC; x++) {
+                                const float t = gv[x] + gsq[j][x];
+                                ppu[j][x] += (t > 0.0f) ? rsq(t) : 0.0f;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    return;
+                }
+                // contiguous rows: one vector load per lane and vector (it may reach up to VEC - 1 slots past its row: those slots
+                // have err = 0 and never leave the lane)
                 uint32_t f = 0;
                 for (; f + U2 <= cnt; f += U2) {
                     float gv[U2][NV][VEC];
@@ -160,7 +175,7 @@ __global__ __launch_bounds__(BLOCK) void dtrain_score_kernel(Batch B, Geom G, co
                     for (int u = 0; u < U2; u++) {
                         const uint32_t row = ((uint32_t)__builtin_amdgcn_readfirstlane((int)hb[f + u]) * Ku) & mask;
 #pragma unroll
-                        for (int j = 0; j < NV; j++) vload<VEC>(g2 + (act[j] ? (size_t)((row + cls[j]) & mask) : (size_t)0), gv[u][j]);
+                        for (int j = 0; j < NV; j++) row_vload<VEC, AL>(g2, row, cls[j], Ku, mask, false, act[j], gv[u][j]);
                     }
 #pragma unroll
                     for (int u = 0; u < U2; u++)
@@ -176,7 +191,7 @@ __global__ __launch_bounds__(BLOCK) void dtrain_score_kernel(Batch B, Geom G, co
                     const uint32_t row = ((uint32_t)__builtin_amdgcn_readfirstlane((int)hb[f]) * Ku) & mask;
                     float gv[NV][VEC];
 #pragma unroll
-                    for (int j = 0; j < NV; j++) vload<VEC>(g2 + (act[j] ? (size_t)((row + cls[j]) & mask) : (size_t)0), gv[j]);
+                    for (int j = 0; j < NV; j++) row_vload<VEC, AL>(g2, row, cls[j], Ku, mask, false, act[j], gv[j]);
 #pragma unroll
                     for (int j = 0; j < NV; j++)
 #pragma unroll
@@ -201,9 +216,16 @@ __global__ __launch_bounds__(BLOCK) void dtrain_score_kernel(Batch B, Geom G, co
                     u[x] = v;
                     q[x] = gsq[j][x];
                 }
-                if (cls[j] < Ku) {
-                    vstore<VEC>(upd_out + e * (uint64_t)Ku + cls[j], u);
-                    vstore<VEC>(gsq_out + e * (uint64_t)Ku + cls[j], q);
+                if (cls[j] + (uint32_t)VEC <= Ku) {
+                    vstoreu<VEC>(upd_out + e * (uint64_t)Ku + cls[j], u);
+                    vstoreu<VEC>(gsq_out + e * (uint64_t)Ku + cls[j], q);
+                } else {                                          // the row's last, partial vector
+#pragma unroll
+                    for (int x = 0; x < VEC; x++)
+                        if (cls[j] + (uint32_t)x < Ku) {
+                            upd_out[e * (uint64_t)Ku + cls[j] + x] = u[x];
+                            gsq_out[e * (uint64_t)Ku + cls[j] + x] = q[x];
+                        }
                 }
             }
         }
@@ -235,7 +257,7 @@ __global__ void dtrain_starts_kernel(const uint32_t *__restrict__ keys, uint32_t
 // One wave per partition of one colour (colour = partition & 1).  Its rows in sorted order, one after the other (the next
 // item's step sizes are fetched while the current row is updated): G += q, w += u / sqrt(G).  Rows of two partitions of one
 // colour never share a slot (a row spills at most into the NEXT partition), so the waves of a launch never meet.
-template <int VEC>
+template <int VEC, bool AL>
 __global__ __launch_bounds__(BLOCK) void dtrain_apply_kernel(float *__restrict__ w, float *__restrict__ g2, uint32_t mask, int K,
                                                               const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                               const uint32_t *__restrict__ pstart, uint32_t NP, uint32_t colour,
@@ -246,6 +268,7 @@ __global__ __launch_bounds__(BLOCK) void dtrain_apply_kernel(float *__restrict__
     const int wv = threadIdx.x / WAVE;
     const uint32_t Ku = (uint32_t)K;
     const bool reg = (ta.l1 != 0.0f) || (ta.l2 != 0.0f);
+    const RowCross crosses(Ku, mask);
     const uint32_t nq = (NP - colour + 1u) / 2u;                 // partitions of this colour
     for (uint64_t q = first_chunk(wv, 1); q < nq; q = next_chunk_after(queue, lane, 1, nq)) {
         const uint32_t p = colour + 2u * (uint32_t)q;
@@ -257,27 +280,38 @@ __global__ __launch_bounds__(BLOCK) void dtrain_apply_kernel(float *__restrict__
             const float s = sfac[e];
             const float decay = 1.0f - s * ta.l2, shrink = s * ta.l1;
             const float *ue = upd + (uint64_t)e * Ku, *qe = gsq + (uint64_t)e * Ku;
-            for (uint32_t c = (uint32_t)lane * VEC; c < Ku; c += WAVE * VEC) {
-                float u[VEC], qv[VEC];
-                vload<VEC>(ue + c, u);
-                vload<VEC>(qe + c, qv);
-                bool any = reg;
+            // one row: G += q, w += u / sqrt(G) for the classes with a step.  The last vector of an example's steps may reach into the
+            // next example's (the arrays are padded): the excess is zeroed.  A row that passes the table's end (wave-uniform, rare)
+            // is worked slot by slot; a contiguous one with one vector load and store per table, the row's last vector, when partial,
+            // stored slot by slot.
+            auto one_row = [&](auto crossing) {
+                constexpr bool CROSS = decltype(crossing)::value;
+                for (uint32_t c = (uint32_t)lane * VEC; c < Ku; c += WAVE * VEC) {
+                    float u[VEC], qv[VEC];
+                    vloadu<VEC>(ue + c, u);
+                    vloadu<VEC>(qe + c, qv);
+                    bool any = reg;
 #pragma unroll
-                for (int x = 0; x < VEC; x++) any = any || (qv[x] != 0.0f) || (u[x] != 0.0f);
-                if (!any) continue;                              // classes already at their label: nothing to add (as VW skips zero updates)
-                const size_t slot = (size_t)((row + c) & mask);
-                float gv[VEC], wv[VEC];
-                vload<VEC>(g2 + slot, gv);
-                vload<VEC>(w + slot, wv);
+                    for (int x = 0; x < VEC; x++) {
+                        if (c + (uint32_t)x >= Ku) { u[x] = 0.0f; qv[x] = 0.0f; }
+                        any = any || (qv[x] != 0.0f) || (u[x] != 0.0f);
+                    }
+                    if (!any) continue;                          // classes already at their label: nothing to add (as VW skips zero updates)
+                    float gv[VEC], wv[VEC];
+                    row_vload<VEC, AL>(g2, row, c, Ku, mask, CROSS, true, gv);
+                    row_vload<VEC, AL>(w, row, c, Ku, mask, CROSS, true, wv);
 #pragma unroll
-                for (int x = 0; x < VEC; x++) {
-                    gv[x] += qv[x];
-                    const float d = (gv[x] > 0.0f) ? u[x] * rsq(gv[x]) : 0.0f;
-                    wv[x] = step_w(wv[x], d, reg, decay, shrink);
+                    for (int x = 0; x < VEC; x++) {
+                        gv[x] += qv[x];
+                        const float d = (gv[x] > 0.0f) ? u[x] * rsq(gv[x]) : 0.0f;
+                        wv[x] = step_w(wv[x], d, reg, decay, shrink);
+                    }
+                    row_vstore<VEC, AL>(g2, row, c, Ku, mask, CROSS, gv);
+                    row_vstore<VEC, AL>(w, row, c, Ku, mask, CROSS, wv);
                 }
-                vstore<VEC>(g2 + slot, gv);
-                vstore<VEC>(w + slot, wv);
-            }
+            };
+            if (!AL && crosses(row)) one_row(std::true_type{});
+            else one_row(std::false_type{});
             // the next row of this partition may be the same row, or overlap it: its loads must see these stores
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -376,13 +410,15 @@ __global__ void dtrain_bounds_kernel(const uint64_t *__restrict__ foff, uint64_t
 
 struct SVariant {
     int vec, nv;
+    bool al;
     const void *fn;
 };
-#define OPAL_SV(VEC, NV, U) {VEC, NV, (const void *)&dtrain_score_kernel<VEC, NV, U>}
+#define OPAL_SV(VEC, NV, U, AL) {VEC, NV, AL, (const void *)&dtrain_score_kernel<VEC, NV, U, AL>}
 const SVariant kScoreVariants[] = {
-    OPAL_SV(1, 1, 8), OPAL_SV(1, 2, 8), OPAL_SV(1, 4, 4), OPAL_SV(1, 8, 2),
-    OPAL_SV(2, 1, 8), OPAL_SV(2, 2, 8), OPAL_SV(2, 4, 4), OPAL_SV(2, 8, 2),
-    OPAL_SV(4, 1, 8), OPAL_SV(4, 2, 8), OPAL_SV(4, 4, 4), OPAL_SV(4, 8, 2),
+    OPAL_SV(1, 1, 8, true),   // K = 1, 3
+    OPAL_SV(2, 1, 8, true),   // K = 2
+    OPAL_SV(4, 1, 8, true), OPAL_SV(4, 2, 8, true), OPAL_SV(4, 4, 4, true), OPAL_SV(4, 8, 2, true),         // K % 4 == 0
+    OPAL_SV(4, 1, 8, false), OPAL_SV(4, 2, 8, false), OPAL_SV(4, 4, 4, false), OPAL_SV(4, 8, 2, false),     // any other K >= 5
 };
 
 struct DTrainState {
@@ -455,9 +491,9 @@ int opal::train_batch_groups(opal_ctx *ctx, const uint8_t *d_reads, uint64_t rea
     for (uint64_t g = 0; g < ng; g++) max_keys = std::max(max_keys, bounds[g + 1] - bounds[g]);
     if (max_keys >= (1ull << 31)) return opal::fail(ctx, OPAL_EINVAL, "opal_train_batch: a group of examples has 2^31 features or more");
     const uint64_t gmax = std::min<uint64_t>(gs, n);
-    rc = grow(ctx, &st->upd, &st->upd_cap, gmax * (uint64_t)K);
+    rc = grow(ctx, &st->upd, &st->upd_cap, gmax * (uint64_t)K + 4);      // + 4: the last example's last vector may be partial
     if (rc) return rc;
-    rc = grow(ctx, &st->gsq, &st->gsq_cap, gmax * (uint64_t)K);
+    rc = grow(ctx, &st->gsq, &st->gsq_cap, gmax * (uint64_t)K + 4);
     if (rc) return rc;
     rc = grow(ctx, &st->sfac, &st->sfac_cap, gmax);
     if (rc) return rc;
@@ -486,13 +522,15 @@ int opal::train_batch_groups(opal_ctx *ctx, const uint8_t *d_reads, uint64_t rea
     const uint32_t mask = ctx->bits == 32 ? 0xffffffffu : ((1u << ctx->bits) - 1u);
     const uint32_t const_idx = OPAL_VW_CONSTANT & mask;
     const uint32_t crow = (uint32_t)(((uint64_t)const_idx * (uint64_t)K) & mask);
-    const int vec = (K % 4 == 0) ? 4 : (K % 2 == 0) ? 2 : 1;
+    const int vec = K >= 4 ? 4 : (K % 2 == 0) ? 2 : 1;                     // 16-byte vectors for every K >= 4 (dword-aligned, see row_vload)
     const int need = (K + WAVE * vec - 1) / (WAVE * vec);
     const int nv = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 8;
     const void *score_fn = kScoreVariants[0].fn;
+    const bool al = K % vec == 0;
     for (const SVariant &v : kScoreVariants)
-        if (v.vec == vec && v.nv == nv) score_fn = v.fn;
-    const void *apply_fn = vec == 4 ? (const void *)&dtrain_apply_kernel<4> : vec == 2 ? (const void *)&dtrain_apply_kernel<2> : (const void *)&dtrain_apply_kernel<1>;
+        if (v.vec == vec && v.nv == nv && v.al == al) score_fn = v.fn;
+    const void *apply_fn = vec == 4 ? (al ? (const void *)&dtrain_apply_kernel<4, true> : (const void *)&dtrain_apply_kernel<4, false>)
+                         : vec == 2 ? (const void *)&dtrain_apply_kernel<2, true> : (const void *)&dtrain_apply_kernel<1, true>;
     int per_cu_s = 0, per_cu_a = 0;
     OPAL_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_s, score_fn, BLOCK, 0));
     OPAL_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_a, apply_fn, BLOCK, 0));

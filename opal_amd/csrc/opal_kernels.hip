@@ -597,7 +597,7 @@ __global__ __launch_bounds__(BLOCK) void predict_kernel(Batch B, Geom G, const f
                 if (lane < HB_PAD) hb[cnt + lane] = const_idx;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                stream_rows<VEC, NV, U, false, NT>(tab, hb, cnt, Ku, mask, loff, acc);
+                stream_rows<VEC, NV, U, 0, NT>(tab, hb, cnt, Ku, mask, loff, acc);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             });

@@ -23,21 +23,6 @@
 
 namespace {
 
-template <int VEC>
-__device__ __forceinline__ void vload(const float *p, float (&o)[VEC])
-{
-    if constexpr (VEC == 4) { const float4 v = *reinterpret_cast<const float4 *>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
-    else if constexpr (VEC == 2) { const float2 v = *reinterpret_cast<const float2 *>(p); o[0] = v.x; o[1] = v.y; }
-    else o[0] = *p;
-}
-template <int VEC>
-__device__ __forceinline__ void vstore(float *p, const float (&o)[VEC])
-{
-    if constexpr (VEC == 4) *reinterpret_cast<float4 *>(p) = make_float4(o[0], o[1], o[2], o[3]);
-    else if constexpr (VEC == 2) *reinterpret_cast<float2 *>(p) = make_float2(o[0], o[1]);
-    else *p = o[0];
-}
-
 // 1/sqrt(x) as one v_rsq_f32 (1 ulp) instead of a correctly rounded sqrt + divide (~60 instructions per element):
 // the per-weight learning rate does not need the last bit, and the sweeps were ALU-bound without it.
 __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
@@ -48,7 +33,9 @@ struct TrainArgs {
     int phases;   // diagnostic: bit0 = run sweep 2, bit1 = run sweep 3 (always 3 outside profiling experiments)
 };
 
-template <int VEC, int NV, int U>
+// AL: K is a multiple of VEC (every lane wraps its own address); otherwise contiguous rows / rows that reach the table's end
+// are told apart (RowCross), see opal_dtrain.hip.
+template <int VEC, int NV, int U, bool AL>
 __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__restrict__ w, float *__restrict__ g2,
                                                        uint32_t mask, int K, uint32_t const_idx,
                                                        const int32_t *__restrict__ labels, TrainArgs ta,
@@ -78,7 +65,7 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
 #pragma unroll
             for (int j = 0; j < NV; j++) {
                 cls[j] = c0 + (uint32_t)(j * WAVE + lane) * VEC;
-                loff[j] = min(cls[j], Ku - VEC);
+                loff[j] = min(cls[j], (Ku - 1u) & ~(uint32_t)(VEC - 1));   // lanes past the row re-read its last vector (which may be partial)
             }
             // ---- sweep 1: scores (identical to predict)
             V acc[NV];
@@ -89,7 +76,11 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
                 if (lane < HB_PAD) hb[cnt + lane] = const_idx;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                stream_rows<VEC, NV, U, true>(w, hb, cnt, Ku, mask, loff, acc);
+                // contiguous rows: the predict kernel's pipeline on unwrapped addresses; a flush that holds a row which passes
+                // the table's end goes slot by slot (the mirror behind the table may be stale while training)
+                if constexpr (AL) stream_rows<VEC, NV, U, 1, false>(w, hb, cnt, Ku, mask, loff, acc);
+                else if (!any_row_crosses(hb, cnt, Ku, mask, lane)) stream_rows<VEC, NV, U, 2, false>(w, hb, cnt, Ku, mask, loff, acc);
+                else stream_rows_wrapped<VEC, NV>(w, hb, cnt, Ku, mask, cls, acc);
                 nfeat += cnt;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -104,9 +95,9 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
                     else if (p > ta.max_label) p = ta.max_label;
                     else if (p < ta.min_label) p = ta.min_label;
                     const uint32_t c = cls[j] + e;
-                    if (cls[j] < Ku && (best_c == 0xffffffffu || p > best)) { best = p; best_c = c; }
+                    if (c < Ku && (best_c == 0xffffffffu || p > best)) { best = p; best_c = c; }
                     const float y = (c == label) ? 1.0f : -1.0f;
-                    err[j][e] = y - p;
+                    err[j][e] = c < Ku ? y - p : 0.0f;          // slots past the row (K not a multiple of VEC) belong to no class
                     gsq[j][e] = 4.0f * err[j][e] * err[j][e];
                     ppu[j][e] = 0.0f;
                 }
@@ -128,11 +119,12 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
             constexpr int U2 = (NV <= 2) ? 4 : (NV == 4 ? 2 : 1);
             const uint32_t thr = (mask - Ku + 1u) & mask;                       // 2^b - K
             const bool tiny = (uint64_t)Ku * 2ull > (uint64_t)mask + 1ull;      // every pair of rows overlaps
+            const RowCross crosses(Ku, mask);                                   // does a row pass the table's end?
             auto independent = [&](const uint32_t (&row)[U2], const uint32_t (&idx)[U2]) -> bool {
                 bool ok = !tiny;
 #pragma unroll
                 for (int x = 0; x < U2; x++) {
-                    ok = ok && (ta.sequential || idx[x] != const_idx);
+                    ok = ok && (ta.sequential || idx[x] != const_idx) && (AL || !crosses(row[x]));   // (rows of a group are contiguous)
 #pragma unroll
                     for (int y = x + 1; y < U2; y++) {
                         const uint32_t d = (row[x] - row[y]) & mask;
@@ -155,10 +147,10 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
 #pragma unroll
                     for (int j = 0; j < NV; j++) {
                         if (act[j]) {
-                            float *gp = g2 + (size_t)((row + cls[j]) & mask);
 #pragma unroll
                             for (int e = 0; e < VEC; e++) {
-                                const float gv = atomicAdd(gp + e, gsq[j][e]) + gsq[j][e];
+                                if (cls[j] + (uint32_t)e >= Ku) continue;
+                                const float gv = atomicAdd(g2 + (size_t)((row + cls[j] + (uint32_t)e) & mask), gsq[j][e]) + gsq[j][e];
                                 ppu[j][e] += (gv > 0.0f) ? rsq(gv) : 0.0f;
                             }
                         }
@@ -166,8 +158,9 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
                     return;
                 }
                 float gv[NV][VEC];
+                const bool cross = !AL && crosses(row);
 #pragma unroll
-                for (int j = 0; j < NV; j++) vload<VEC>(g2 + (act[j] ? (size_t)((row + cls[j]) & mask) : (size_t)0), gv[j]);
+                for (int j = 0; j < NV; j++) row_vload<VEC, AL>(g2, row, cls[j], Ku, mask, cross, act[j], gv[j]);
 #pragma unroll
                 for (int j = 0; j < NV; j++) {
 #pragma unroll
@@ -175,7 +168,7 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
                         gv[j][e] += gsq[j][e];
                         ppu[j][e] += (gv[j][e] > 0.0f) ? rsq(gv[j][e]) : 0.0f;
                     }
-                    if (act[j]) vstore<VEC>(g2 + (size_t)((row + cls[j]) & mask), gv[j]);
+                    if (act[j]) row_vstore<VEC, AL>(g2, row, cls[j], Ku, mask, cross, gv[j]);
                 }
             };
             if (ta.phases & 1)
@@ -195,7 +188,7 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
                             for (int u = 0; u < U2; u++) {
 #pragma unroll
                                 for (int j = 0; j < NV; j++)   // idle lanes read slot 0 (see the note on branch-free loads)
-                                    vload<VEC>(g2 + (act[j] ? (size_t)((row[u] + cls[j]) & mask) : (size_t)0), gv[u][j]);
+                                    row_vload<VEC, AL>(g2, row[u], cls[j], Ku, mask, false, act[j], gv[u][j]);
                             }
 #pragma unroll
                             for (int u = 0; u < U2; u++)
@@ -206,7 +199,7 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
                                         gv[u][j][e] += gsq[j][e];
                                         ppu[j][e] += (gv[u][j][e] > 0.0f) ? rsq(gv[u][j][e]) : 0.0f;
                                     }
-                                    if (act[j]) vstore<VEC>(g2 + (size_t)((row[u] + cls[j]) & mask), gv[u][j]);
+                                    if (act[j]) row_vstore<VEC, AL>(g2, row[u], cls[j], Ku, mask, false, gv[u][j]);
                                 }
                         } else {
 #pragma unroll
@@ -248,16 +241,16 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
 #pragma unroll
                     for (int j = 0; j < NV; j++) {
                         if (act[j]) {
-                            const size_t slot = (size_t)((row + cls[j]) & mask);
-                            float gv[VEC];
-                            vload<VEC>(g2 + slot, gv);
 #pragma unroll
                             for (int e = 0; e < VEC; e++) {
-                                const float d = (gv[e] > 0.0f) ? upd[j][e] * rsq(gv[e]) : 0.0f;
+                                if (cls[j] + (uint32_t)e >= Ku) continue;
+                                const size_t slot = (size_t)((row + cls[j] + (uint32_t)e) & mask);
+                                const float gve = g2[slot];
+                                const float d = (gve > 0.0f) ? upd[j][e] * rsq(gve) : 0.0f;
                                 if (!reg) {
-                                    atomicAdd(w + slot + e, d);
+                                    atomicAdd(w + slot, d);
                                 } else {   // decay and soft threshold are not additive: compare-and-swap until this example's step lands
-                                    unsigned int *pw = reinterpret_cast<unsigned int *>(w + slot + e);
+                                    unsigned int *pw = reinterpret_cast<unsigned int *>(w + slot);
                                     unsigned int seen = *pw, assumed;
                                     do {
                                         assumed = seen;
@@ -270,11 +263,11 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
                     return;
                 }
                 float gv[NV][VEC], wo[NV][VEC];
+                const bool cross = !AL && crosses(row);
 #pragma unroll
                 for (int j = 0; j < NV; j++) {
-                    const size_t slot = act[j] ? (size_t)((row + cls[j]) & mask) : (size_t)0;
-                    vload<VEC>(g2 + slot, gv[j]);
-                    vload<VEC>(w + slot, wo[j]);
+                    row_vload<VEC, AL>(g2, row, cls[j], Ku, mask, cross, act[j], gv[j]);
+                    row_vload<VEC, AL>(w, row, cls[j], Ku, mask, cross, act[j], wo[j]);
                 }
 #pragma unroll
                 for (int j = 0; j < NV; j++) {
@@ -283,7 +276,7 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
                         const float d = (gv[j][e] > 0.0f) ? upd[j][e] * rsq(gv[j][e]) : 0.0f;
                         wo[j][e] = finish_w(wo[j][e], d);
                     }
-                    if (act[j]) vstore<VEC>(w + (size_t)((row + cls[j]) & mask), wo[j]);
+                    if (act[j]) row_vstore<VEC, AL>(w, row, cls[j], Ku, mask, cross, wo[j]);
                 }
             };
             if (ta.phases & 2)
@@ -303,9 +296,8 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
                             for (int u = 0; u < U2; u++) {
 #pragma unroll
                                 for (int j = 0; j < NV; j++) {
-                                    const size_t slot = act[j] ? (size_t)((row[u] + cls[j]) & mask) : (size_t)0;
-                                    vload<VEC>(g2 + slot, gv[u][j]);
-                                    vload<VEC>(w + slot, wo[u][j]);
+                                    row_vload<VEC, AL>(g2, row[u], cls[j], Ku, mask, false, act[j], gv[u][j]);
+                                    row_vload<VEC, AL>(w, row[u], cls[j], Ku, mask, false, act[j], wo[u][j]);
                                 }
                             }
 #pragma unroll
@@ -317,7 +309,7 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
                                         const float d = (gv[u][j][e] > 0.0f) ? upd[j][e] * rsq(gv[u][j][e]) : 0.0f;
                                         wo[u][j][e] = finish_w(wo[u][j][e], d);
                                     }
-                                    if (act[j]) vstore<VEC>(w + (size_t)((row[u] + cls[j]) & mask), wo[u][j]);
+                                    if (act[j]) row_vstore<VEC, AL>(w, row[u], cls[j], Ku, mask, false, wo[u][j]);
                                 }
                         } else {
 #pragma unroll
@@ -345,22 +337,24 @@ __global__ __launch_bounds__(BLOCK) void train_kernel(Batch B, Geom G, float *__
 
 struct TVariant {
     int vec, nv;
+    bool al;
     const void *fn;
 };
-#define OPAL_TV(VEC, NV, U) {VEC, NV, (const void *)&train_kernel<VEC, NV, U>}
+#define OPAL_TV(VEC, NV, U, AL) {VEC, NV, AL, (const void *)&train_kernel<VEC, NV, U, AL>}
 const TVariant kTrainVariants[] = {
-    OPAL_TV(1, 1, 8), OPAL_TV(1, 2, 8), OPAL_TV(1, 4, 4), OPAL_TV(1, 8, 2),
-    OPAL_TV(2, 1, 8), OPAL_TV(2, 2, 8), OPAL_TV(2, 4, 4), OPAL_TV(2, 8, 2),
-    OPAL_TV(4, 1, 8), OPAL_TV(4, 2, 8), OPAL_TV(4, 4, 4), OPAL_TV(4, 8, 2),
+    OPAL_TV(1, 1, 8, true),   // K = 1, 3
+    OPAL_TV(2, 1, 8, true),   // K = 2
+    OPAL_TV(4, 1, 8, true), OPAL_TV(4, 2, 8, true), OPAL_TV(4, 4, 4, true), OPAL_TV(4, 8, 2, true),         // K % 4 == 0
+    OPAL_TV(4, 1, 8, false), OPAL_TV(4, 2, 8, false), OPAL_TV(4, 4, 4, false), OPAL_TV(4, 8, 2, false),     // any other K >= 5
 };
 
 const TVariant &pick_train_variant(int K)
 {
-    const int vec = (K % 4 == 0) ? 4 : (K % 2 == 0) ? 2 : 1;
+    const int vec = K >= 4 ? 4 : (K % 2 == 0) ? 2 : 1;   // 16-byte vectors for every K >= 4 (dword-aligned, see row_vload)
     const int need = (K + WAVE * vec - 1) / (WAVE * vec);
     const int nv = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 8;
     for (const TVariant &v : kTrainVariants)
-        if (v.vec == vec && v.nv == nv) return v;
+        if (v.vec == vec && v.nv == nv && v.al == (K % vec == 0)) return v;
     return kTrainVariants[0];
 }
 

@@ -25,10 +25,12 @@ def _patterns(amd, golden_dir, fname, k):
         return amd.parse_patterns(f.readlines(), k)
 
 
-# (1565, 16) and (2100, 17): more classes than one register chunk holds (4 and 2 chunks) on tables small enough that rows of
-# one example overlap across chunks: the rule is chunk-wise there (oracle/opal_oracle.c orc_train restates exactly that)
+# (2100, 17) and (2101, 17): more classes than one register chunk holds (2 chunks of 2048) on tables small enough that rows of
+# one example overlap across chunks: the rule is chunk-wise there (oracle/opal_oracle.c orc_train restates exactly that).
+# Odd K (7, 355, 1565, 2101): rows start at any slot, their 16-byte vectors are dword aligned, the last one is partial, and on
+# these small tables many rows pass the table's end (the slot-by-slot path).
 @pytest.mark.parametrize("K,bits,l1,l2", [(10, 12, 0.0, 0.0), (356, 16, 0.0, 0.0), (7, 14, 1e-4, 1e-3), (1564, 18, 0.0, 0.0),
-                                          (1565, 16, 0.0, 0.0), (2100, 17, 0.0, 0.0)])
+                                          (355, 20, 0.0, 0.0), (1565, 16, 0.0, 0.0), (2100, 17, 0.0, 0.0), (2101, 17, 1e-4, 0.0)])
 def test_sequential_training_matches_oracle(amd, oracle, golden_dir, K, bits, l1, l2):
     rng = np.random.default_rng(K + bits)
     pos = _patterns(amd, golden_dir, "patterns_k64_t16_m1_s7.txt", 64)
