@@ -193,6 +193,14 @@ int opal_get_weights(opal_ctx *ctx, float *dst, int dst_is_device);
 /* Loads a model stored as nnz (slot index, weight) pairs (host arrays); all other slots are 0.                */
 int opal_load_weights_sparse(opal_ctx *ctx, const uint32_t *idx, const float *val, uint64_t nnz, int K, int bits);
 
+/* The learner's resume state: what `--save_resume` adds to a vw regressor (opal.py:310) is, for this rule, the AdaGrad
+ * accumulator G of every slot.  opal_get_accumulators copies the 2^bits accumulators out (after opal_train_begin /
+ * opal_train_batch); opal_load_accumulators_sparse installs nnz (slot, G) pairs (all other slots 0) next to weights that are
+ * already loaded with the same K and bits, so that opal_train_begin(resume=1) continues the rule where the saved run
+ * stopped instead of restarting the accumulators at zero.  [VW-unpinned: the reference has no resume path of its own]   */
+int opal_get_accumulators(opal_ctx *ctx, float *dst, int dst_is_device);
+int opal_load_accumulators_sparse(opal_ctx *ctx, const uint32_t *idx, const float *val, uint64_t nnz);
+
 /* GPU-side FASTA ingest.  Replaces fasta_functions.fasta_reader over open(path,'r')
  * (util/fasta_functions.py:9-43, universal newlines, '+' mutes up to the next '>', text before the first '>' is
  * dropped, an empty last record is dropped) followed by packing, for a whole file whose bytes are already in HBM:

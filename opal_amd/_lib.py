@@ -52,6 +52,8 @@ PROTOTYPES = {
     "opal_train_batch": (_int, [_vp, _vp, _u64, _vp, _vp, _vp, _u64, _int, _f32, _f32, _f32, _int, _vp]),
     "opal_get_weights": (_int, [_vp, _vp, _int]),
     "opal_load_weights_sparse": (_int, [_vp, _vp, _vp, _u64, _int, _int]),
+    "opal_get_accumulators": (_int, [_vp, _vp, _int]),
+    "opal_load_accumulators_sparse": (_int, [_vp, _vp, _vp, _u64]),
 }
 
 _lib = None

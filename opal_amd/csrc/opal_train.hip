@@ -510,6 +510,53 @@ extern "C" int opal_load_weights_sparse(opal_ctx *ctx, const uint32_t *idx, cons
     return OPAL_OK;
 }
 
+extern "C" int opal_get_accumulators(opal_ctx *ctx, float *dst, int dst_is_device)
+{
+    if (!ctx) return opal::fail(nullptr, OPAL_EINVAL, "opal_get_accumulators: null ctx");
+    if (!ctx->d_g2 || !ctx->g2_valid || ctx->K == 0) return opal::fail(ctx, OPAL_ESTATE, "opal_get_accumulators: no training state (call opal_train_begin first)");
+    if (!dst) return opal::fail(ctx, OPAL_EINVAL, "opal_get_accumulators: null dst");
+    OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    OPAL_HIP_CHECK(ctx, hipMemcpyAsync(dst, ctx->d_g2, ctx->n_slots * sizeof(float),
+                                       dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    OPAL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return OPAL_OK;
+}
+
+extern "C" int opal_load_accumulators_sparse(opal_ctx *ctx, const uint32_t *idx, const float *val, uint64_t nnz)
+{
+    if (!ctx) return opal::fail(nullptr, OPAL_EINVAL, "opal_load_accumulators_sparse: null ctx");
+    if (!ctx->d_w || ctx->K == 0) return opal::fail(ctx, OPAL_ESTATE, "opal_load_accumulators_sparse: load the weights first");
+    if (nnz && (!idx || !val)) return opal::fail(ctx, OPAL_EINVAL, "opal_load_accumulators_sparse: null arrays");
+    OPAL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    OPAL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = alloc_floats(ctx, &ctx->d_g2, &ctx->g2_alloc_floats, ctx->n_slots);
+    if (rc) return rc;
+    ctx->g2_valid = false;
+    OPAL_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_g2, 0, ctx->n_slots * sizeof(float), ctx->stream));
+    if (nnz) {
+        struct Staging {
+            uint32_t *idx = nullptr;
+            float *val = nullptr;
+            ~Staging() { if (idx) (void)hipFree(idx); if (val) (void)hipFree(val); }
+        } stg;
+        hipError_t e = hipMalloc((void **)&stg.idx, nnz * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&stg.val, nnz * sizeof(float));
+        if (e != hipSuccess) return opal::fail(ctx, OPAL_ENOMEM, std::string("opal_load_accumulators_sparse: hipMalloc failed: ") + hipGetErrorString(e));
+        e = hipMemcpyAsync(stg.idx, idx, nnz * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(stg.val, val, nnz * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            const int grid = (int)std::min<uint64_t>((nnz + 255) / 256, 65536);
+            hipLaunchKernelGGL(scatter_weights_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->d_g2, stg.idx, stg.val, nnz, ctx->n_slots);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return opal::fail(ctx, OPAL_EHIP, std::string("opal_load_accumulators_sparse: ") + hipGetErrorString(e));
+    }
+    OPAL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->g2_valid = true;     // opal_train_begin(resume=1) keeps these accumulators
+    return OPAL_OK;
+}
+
 // ------------------------------------------------------------------------------------------ evaluation counts
 // Replaces the per-line string compare + pandas groupby of opal.evaluate_predictions (reference opal.py:111-131):
 // per reference class, how many fragments there are and how many were predicted correctly.  Classes are dense

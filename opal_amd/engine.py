@@ -343,6 +343,21 @@ class Engine:
         check(lib().opal_get_weights(self._h, out.data_ptr(), 1), self._h)
         return out
 
+    def get_accumulators(self):
+        """The learner's 2^bits AdaGrad accumulators (torch cuda tensor): the resume state a `--save_resume` model carries
+        (reference opal.py:310)."""
+        t = self.torch
+        out = t.empty(1 << self.bits, dtype=t.float32, device=self.device)
+        check(lib().opal_get_accumulators(self._h, out.data_ptr(), 1), self._h)
+        return out
+
+    def load_accumulators_sparse(self, idx: np.ndarray, val: np.ndarray):
+        """Installs saved accumulators next to the loaded weights; train_begin(K, bits, resume=True) then continues the rule."""
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        val = np.ascontiguousarray(val, dtype=np.float32)
+        assert idx.size == val.size
+        check(lib().opal_load_accumulators_sparse(self._h, idx.ctypes.data, val.ctypes.data, idx.size), self._h)
+
     def load_weights_sparse(self, idx: np.ndarray, val: np.ndarray, K: int, bits: int):
         idx = np.ascontiguousarray(idx, dtype=np.uint32)
         val = np.ascontiguousarray(val, dtype=np.float32)

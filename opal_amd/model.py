@@ -5,10 +5,15 @@ The reference's file is whatever `vw -f` writes; VW is absent here (parity unpin
 native container that holds exactly what the scoring kernel needs: bits, K (--oaa), the VW switches, and the
 compact weight table either dense (2^bits float32) or as (slot, weight) pairs when that is smaller.
 
-layout (little endian):  magic "OPALHIP1" | u32 version=1 | u32 bits | u32 K | u32 flags | f32 min_label | f32 max_label
-                         | u64 nnz | u32 dense(0/1) | u32 reserved | payload
+layout (little endian):  magic "OPALHIP1" | u32 version | u32 bits | u32 K | u32 flags | f32 min_label | f32 max_label
+                         | u64 nnz | u32 dense(0/1) | u32 batches | payload [| resume section]
                          payload dense : float32[2^bits]          payload sparse: uint32 slot[nnz], float32 weight[nnz]
 flags: bit0 hash_all, bit1 add_constant, bit2 clip
+version 1: weights only (what predict needs; the default, files as small as they can be).
+version 2 (written by `train --save-resume`, the counterpart of vw's --save_resume at reference opal.py:310): the payload is
+followed by the learner's state, so that training can go on where it stopped:
+                         magic "OPALRES2" | u64 g_nnz | uint32 slot[g_nnz] | float32 G[g_nnz]      (AdaGrad accumulators, sparse)
+and `batches` counts the training batches the model has seen (a resumed run draws its next batch with seed 421 + batches).
 """
 import struct
 
@@ -51,14 +56,19 @@ def _nonzero_chunks(w, chunk=1 << 27):
             np.concatenate(val_parts) if val_parts else np.zeros(0, np.float32))
 
 
-def save_model(path, w, K, bits, hash_all=False, add_constant=True, clip=True, min_label=-1.0, max_label=1.0):
-    """w: the 2^bits table (numpy float32 or torch tensor, any device).  Returns the number of non-zero weights."""
+RESUME_MAGIC = b"OPALRES2"
+
+
+def save_model(path, w, K, bits, hash_all=False, add_constant=True, clip=True, min_label=-1.0, max_label=1.0, g=None, batches=0):
+    """w: the 2^bits table (numpy float32 or torch tensor, any device).  g (optional): the learner's 2^bits accumulators;
+    with it the file is a version-2 container that training can resume from.  Returns the number of non-zero weights."""
     assert w.shape[0] == (1 << bits)
+    assert g is None or g.shape[0] == (1 << bits)
     nnz = _count_nonzero(w)
     dense = nnz * 8 >= (1 << bits) * 4
     flags = int(bool(hash_all)) | (int(bool(add_constant)) << 1) | (int(bool(clip)) << 2)
     with open(path, "wb") as f:
-        f.write(_HDR.pack(MAGIC, 1, bits, K, flags, min_label, max_label, nnz, int(dense), 0))
+        f.write(_HDR.pack(MAGIC, 1 if g is None else 2, bits, K, flags, min_label, max_label, nnz, int(dense), int(batches) if g is not None else 0))
         if dense:
             chunk = 1 << 27                                    # 512 MiB pieces: bounded host memory for 8 GiB tables
             for s in range(0, w.shape[0], chunk):
@@ -69,6 +79,11 @@ def save_model(path, w, K, bits, hash_all=False, add_constant=True, clip=True, m
             idx, val = _nonzero_chunks(w)
             idx.tofile(f)
             val.tofile(f)
+        if g is not None:
+            gidx, gval = _nonzero_chunks(g)
+            f.write(RESUME_MAGIC + struct.pack("<Q", gidx.size))
+            gidx.tofile(f)
+            gval.tofile(f)
     return nnz
 
 
@@ -77,11 +92,12 @@ def read_header(path):
         raw = f.read(_HDR.size)
     if len(raw) < _HDR.size or raw[:8] != MAGIC:
         raise RuntimeError("%s is not an opal_amd model (a VW binary regressor cannot be read: no vw to pin its layout)" % path)
-    magic, version, bits, K, flags, minl, maxl, nnz, dense, _ = _HDR.unpack(raw)
-    if version != 1:
+    magic, version, bits, K, flags, minl, maxl, nnz, dense, batches = _HDR.unpack(raw)
+    if version not in (1, 2):
         raise RuntimeError("unsupported opal_amd model version %d" % version)
     return dict(bits=bits, K=K, hash_all=bool(flags & 1), add_constant=bool(flags & 2), clip=bool(flags & 4),
-                min_label=minl, max_label=maxl, nnz=nnz, dense=bool(dense))
+                min_label=minl, max_label=maxl, nnz=nnz, dense=bool(dense), version=version, resumable=version == 2,
+                batches=batches if version == 2 else 0)
 
 
 def model_kind(path):
@@ -95,11 +111,15 @@ def model_kind(path):
     return "vw-binary"
 
 
-def load_model(path, engine):
+def load_model(path, engine, resume=False):
     """Loads the model into the engine's GPU context (weights + VW switches) and returns the header dict.  Dispatches on
     the file's first bytes: the native container, a VW `--readable_model` text dump (imported, VW-unverified), or a VW
-    binary regressor, whose header is parsed as far as it can be and then refused with what was found."""
+    binary regressor, whose header is parsed as far as it can be and then refused with what was found.
+    resume=True also installs the learner's accumulators (version-2 container only: RuntimeError otherwise), so that
+    engine.train_begin(K, bits, resume=True) continues the training the file was saved from."""
     kind = model_kind(path)
+    if resume and kind != "opal":
+        raise RuntimeError("%s holds no resume state (only a model written by `train --save-resume` does)" % path)
     if kind == "vw-text":
         m = import_vw_readable_model(path)
         engine.load_weights_sparse(m["idx"], m["val"], m["K"], m["bits"])
@@ -122,6 +142,18 @@ def load_model(path, engine):
             if idx.size != h["nnz"] or val.size != h["nnz"]:
                 raise RuntimeError("truncated model file " + path)
             engine.load_weights_sparse(idx, val, h["K"], h["bits"])
+        if resume:
+            if not h["resumable"]:
+                raise RuntimeError("%s holds no resume state (only a model written by `train --save-resume` does)" % path)
+            sec = f.read(16)
+            if len(sec) != 16 or sec[:8] != RESUME_MAGIC:
+                raise RuntimeError("truncated model file " + path)
+            g_nnz = struct.unpack("<Q", sec[8:])[0]
+            gidx = np.fromfile(f, dtype=np.uint32, count=g_nnz)
+            gval = np.fromfile(f, dtype=np.float32, count=g_nnz)
+            if gidx.size != g_nnz or gval.size != g_nnz:
+                raise RuntimeError("truncated model file " + path)
+            engine.load_accumulators_sparse(gidx, gval)
     engine.set_vw_options(h["hash_all"], h["add_constant"], h["clip"], h["min_label"], h["max_label"])
     return h
 

@@ -277,15 +277,31 @@ def train(ref_dir, model_dir, args, engine=None):
     dico = os.path.join(model_dir, "vw-dico.txt")
     model_prefix = os.path.join(model_dir, "vw-model")
     pattern_file = os.path.join(model_dir, "patterns.txt")
-    ldpc.ldpc_write(k=kmer, t=row_weight, _m=num_hash, d=pattern_file)     # reference opal.py:301-302
+    final_model_file = model_prefix + "_final.model"
+    # --resume (no counterpart in the reference CLI, which passes --save_resume to vw at opal.py:310 but never reads the state
+    # back): go on training the model of model_dir, written by an earlier `train --save-resume`, with ITS patterns.txt
+    resume = bool(getattr(args, "resume", False))
+    save_resume = bool(getattr(args, "save_resume", False))
+    if resume:
+        if not (os.path.exists(pattern_file) and os.path.exists(final_model_file)):
+            raise RuntimeError("--resume needs the patterns.txt and vw-model_final.model of an earlier run in {}".format(model_dir))
+    else:
+        ldpc.ldpc_write(k=kmer, t=row_weight, _m=num_hash, d=pattern_file)     # reference opal.py:301-302
     with open(pattern_file) as f:
         pos = parse_patterns(f.readlines(), kmer)
 
     eng = engine or Engine(int(os.environ.get("LOCAL_RANK", "0")))
     eng.set_patterns(pos, kmer)
     eng.set_vw_options()
-    eng.train_begin(num_labels, bits)
-    final_model_file = model_prefix + "_final.model"
+    batches_done = 0
+    if resume:
+        hdr = model_io.load_model(final_model_file, eng, resume=True)
+        if hdr["K"] != num_labels:
+            raise ValueError("--resume: the model has {} classes, the training set {}".format(hdr["K"], num_labels))
+        bits, batches_done = hdr["bits"], hdr["batches"]
+        eng.train_begin(num_labels, bits, resume=True)
+    else:
+        eng.train_begin(num_labels, bits)
     # The reference's learner is one vw process fed in order: the same inputs give the same model.  The default schedule
     # here keeps that property (deterministic groups, opal_dtrain.hip: bit-identical models run to run); `concurrent`
     # is the Hogwild schedule (as fast or faster on later passes, models differ slightly between runs), `sequential` the
@@ -315,7 +331,7 @@ def train(ref_dir, model_dir, args, engine=None):
     HOLDOUT_PERIOD, EARLY_TERMINATE = 10, 3
     stream = []                                              # per batch: (train views, labels, holdout views, labels)
     seen = 0
-    seed = 420
+    seed = 420 + batches_done                                # a resumed run goes on with the seeds the first run would have used
     rng = Rng()
     for i in range(num_batches):
         seed = seed + 1                                      # 421, 422, ... (reference opal.py:329)
@@ -370,7 +386,10 @@ def train(ref_dir, model_dir, args, engine=None):
                     break
     if w is None:
         w = eng.get_weights()
-    nnz = model_io.save_model(final_model_file, w, num_labels, bits)
+    # --save-resume: the file also carries the accumulators (of the table as trained to the end; with several passes the saved
+    # weights may be an earlier pass's, the best on the holdout set) and the number of batches seen
+    nnz = model_io.save_model(final_model_file, w, num_labels, bits, g=eng.get_accumulators() if save_resume else None,
+                              batches=batches_done + num_batches)
     log.write("saved %s (%d non-zero weights)\n" % (final_model_file, nnz))
     log.close()
     print("------------------------------------------------\nTotal wall clock runtime (sec): {}\n"
@@ -611,6 +630,13 @@ def build_parser():
             p.add_argument(pos_name, help=pos_help)
         if name == "simulate":
             p.add_argument("--do-not-fragment", action="store_true", help="use the test fasta as it is")
+        if name == "train":
+            p.add_argument("--save-resume", action="store_true",
+                           help="also store the learner's state (AdaGrad accumulators) in vw-model_final.model, as vw's --save_resume "
+                                "does, so that `train --resume` can go on from it (larger file)")
+            p.add_argument("--resume", action="store_true",
+                           help="continue training the model of model_dir (written with --save-resume) on further batches, "
+                                "with its patterns.txt and dictionary")
         if name in ("train", "simulate"):
             p.add_argument("--train-mode", choices=sorted(TRAIN_MODES), default=None,
                            help="learner schedule (not in the reference, whose vw process is sequential): deterministic = same model "

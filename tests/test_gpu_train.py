@@ -25,6 +25,22 @@ def _patterns(amd, golden_dir, fname, k):
         return amd.parse_patterns(f.readlines(), k)
 
 
+def _margins(oracle, seqs, pos, w, K, bits):
+    """Per fragment: the gap between the two largest (clipped) scores against table w, i.e. how decided the prediction is."""
+    _, sc, _ = oracle.predict(seqs, 64, pos, True, w, K, bits)
+    if K == 1:
+        return np.full(len(seqs), np.inf)
+    top = np.partition(sc.astype(np.float64), K - 2, axis=1)[:, K - 2:]
+    return top[:, 1] - top[:, 0]
+
+
+def _rows_of(oracle, seq, pos, K, bits):
+    """The table slots fragment `seq` touches (its k-mer rows; not the constant row)."""
+    mask = (1 << bits) - 1
+    h = np.unique(oracle.feature_hashes(seq, 64, pos, True, hash_all=False).astype(np.uint64) & np.uint64(mask))
+    return np.unique(((h[:, None] * np.uint64(K) + np.arange(K, dtype=np.uint64)[None, :]) & np.uint64(mask)).reshape(-1))
+
+
 # (2100, 17) and (2101, 17): more classes than one register chunk holds (2 chunks of 2048) on tables small enough that rows of
 # one example overlap across chunks: the rule is chunk-wise there (oracle/opal_oracle.c orc_train restates exactly that).
 # Odd K (7, 355, 1565, 2101): rows start at any slot, their 16-byte vectors are dword aligned, the last one is partial, and on
@@ -49,10 +65,16 @@ def test_sequential_training_matches_oracle(amd, oracle, golden_dir, K, bits, l1
     g2 = np.zeros(1 << bits, dtype=np.float32)
     for p in range(2):                         # two passes, like --num-passes 2
         pred = eng.train_batch(batch, labels, True, eta=0.5, l1=l1, l2=l2, sequential=True, want_pred=True)
-        opred = oracle.train(seqs, labels, 64, pos, True, w, g2, K, bits, eta=0.5, l1=l1, l2=l2)
+        # the oracle one example at a time, so that the margin of every progressive prediction is known: the two may
+        # differ only where the oracle's two best scores are closer than 1e-5 (GPU expf / v_rsq_f32 against libm)
+        opred, margin = np.zeros(len(seqs), dtype=np.int32), np.zeros(len(seqs))
+        for i in range(len(seqs)):
+            margin[i] = _margins(oracle, seqs[i:i + 1], pos, w, K, bits)[0]
+            opred[i] = oracle.train(seqs[i:i + 1], labels[i:i + 1], 64, pos, True, w, g2, K, bits, eta=0.5, l1=l1, l2=l2)[0]
         gw = eng.get_weights(to_host=True)
         assert np.allclose(gw, w, rtol=2e-4, atol=1e-6), (p, np.abs(gw - w).max())
-        assert (pred.cpu().numpy() == opred).mean() > 0.9      # ties between near-equal scores may flip
+        differ = pred.cpu().numpy() != opred
+        assert not (differ & (margin >= 1e-5)).any(), (p, np.flatnonzero(differ).tolist(), margin[differ].tolist())
     assert np.count_nonzero(w) > 0
     # the trained table is immediately usable by predict (mirror padding refreshed)
     cls, sc = eng.predict(batch, True, want_scores=True)
@@ -62,7 +84,8 @@ def test_sequential_training_matches_oracle(amd, oracle, golden_dir, K, bits, l1
 
 
 @pytest.mark.parametrize("K,bits,l1,l2,group", [(10, 12, 0.0, 0.0, 7), (356, 16, 0.0, 0.0, 16), (7, 14, 1e-4, 1e-3, 5),
-                                                (1564, 18, 0.0, 0.0, 64), (1565, 16, 0.0, 0.0, 9), (2100, 17, 0.0, 0.0, 30)])
+                                                (1564, 18, 0.0, 0.0, 64), (355, 20, 0.0, 0.0, 11), (1565, 16, 0.0, 0.0, 9),
+                                                (2100, 17, 0.0, 0.0, 30), (2101, 17, 0.0, 0.0, 13)])
 def test_deterministic_training_matches_oracle_and_itself(amd, oracle, golden_dir, K, bits, l1, l2, group):
     """opal_train_batch mode 2 (deterministic groups, opal_dtrain.hip): (1) against the CPU statement of the same rule
     (oracle.train_groups) at 2e-4 (GPU expf / v_rsq_f32 against libm), over several groups, a short last group, repeated
@@ -94,12 +117,21 @@ def test_deterministic_training_matches_oracle_and_itself(amd, oracle, golden_di
             gw = eng.get_weights(to_host=True)
             got.append((gw, pred.cpu().numpy().copy()))
             if rep == 0:
-                opred = oracle.train_groups(seqs, labels, 64, pos, True, w, g2, K, bits, group, pshift, eta=0.5, l1=l1, l2=l2)
-                # 2e-4 everywhere but for a handful of slots: the all-A fragment updates ONE row 548 times per pass, scores sit on
-                # the clip boundary there, and expf / v_rsq_f32 against libm decide on which side (seen: 4 slots at 5e-4)
-                off_tol = np.abs(gw - w) > 2e-4 * np.abs(w) + 1e-6
-                assert off_tol.mean() < 1e-3 and np.allclose(gw, w, rtol=2e-3, atol=1e-6), (p, int(off_tol.sum()), np.abs(gw - w).max())
-                assert (got[-1][1] == opred).mean() > 0.9      # ties between near-equal scores may flip
+                # the oracle a group at a time (the same thing as one call: groups are consecutive examples), so that the
+                # margin of every progressive prediction against the table its group started from is known
+                opred, margin = np.zeros(len(seqs), dtype=np.int32), np.zeros(len(seqs))
+                for a in range(0, len(seqs), group):
+                    margin[a:a + group] = _margins(oracle, seqs[a:a + group], pos, w, K, bits)
+                    opred[a:a + group] = oracle.train_groups(seqs[a:a + group], labels[a:a + group], 64, pos, True, w, g2, K, bits,
+                                                             group, pshift, eta=0.5, l1=l1, l2=l2)
+                # 2e-4 everywhere but on the rows of the all-A fragment (seqs[2] and its repeat): it updates the same four rows
+                # 137 times each per pass, their scores sit on the clip boundary, and expf / v_rsq_f32 against libm decide
+                # on which side (seen: 4 slots at 5e-4).  WHICH slots may differ is stated, not how many:
+                off_tol = np.flatnonzero(np.abs(gw - w) > 2e-4 * np.abs(w) + 1e-6)
+                assert np.isin(off_tol, _rows_of(oracle, seqs[2], pos, K, bits)).all(), (p, off_tol.tolist())
+                assert np.allclose(gw, w, rtol=2e-3, atol=1e-6), (p, np.abs(gw - w).max())
+                differ = got[-1][1] != opred
+                assert not (differ & (margin >= 1e-5)).any(), (p, np.flatnonzero(differ).tolist(), margin[differ].tolist())
         runs.append(got)
         if rep == 0:
             assert np.count_nonzero(w) > 0
@@ -264,6 +296,24 @@ def test_cli_train_is_reproducible_by_default(amd, tmp_path):
                "--num-batches", "2", "--bits", "24", "--train-mode", "concurrent"])
     assert "schedule=concurrent" in open(tmp_path / "c" / "vw-model_vwps.log").readline()
     assert os.path.getsize(tmp_path / "c" / "vw-model_final.model") > 10_000
+    # --save-resume / --resume: two batches in one run == one batch, saved with the learner's state, then one more batch in a
+    # second process-worth of state (fresh engine, model and accumulators from the file, seeds continued): identical files
+    np.random.seed(4)
+    opal.main(["train", str(tmp_path / "train"), str(tmp_path / "d"), "-r", "-l", "200", "-c", "3", "--num-hash", "1",
+               "--num-batches", "2", "--bits", "24", "--save-resume"])
+    np.random.seed(4)
+    opal.main(["train", str(tmp_path / "train"), str(tmp_path / "e"), "-r", "-l", "200", "-c", "3", "--num-hash", "1",
+               "--num-batches", "1", "--bits", "24", "--save-resume"])
+    opal.main(["train", str(tmp_path / "train"), str(tmp_path / "e"), "-r", "-l", "200", "-c", "3", "--num-hash", "1",
+               "--num-batches", "1", "--save-resume", "--resume"])
+    d, e = (open(tmp_path / x / "vw-model_final.model", "rb").read() for x in ("d", "e"))
+    assert d == e and len(d) > len(blobs[0])
+    # the weights section of the resumable file is the plain file's
+    from opal_amd import model as model_io
+    assert model_io.read_header(str(tmp_path / "d" / "vw-model_final.model"))["batches"] == 2
+    with pytest.raises(RuntimeError, match="no resume state"):
+        opal.main(["train", str(tmp_path / "train"), str(tmp_path / "a"), "-r", "-l", "200", "-c", "3", "--num-hash", "1",
+                   "--num-batches", "1", "--resume"])
 
 
 def test_cli_train_multipass_holdout_and_early_stop(amd, tmp_path):
@@ -469,3 +519,54 @@ def test_cli_predict_two_ranks_equals_one(amd, tmp_path):
     for name in ("test.fragments-db.preds.vw", "test.fragments-db.preds.taxid"):
         a, b = (tmp_path / "one" / name).read_bytes(), (tmp_path / "two" / name).read_bytes()
         assert a == b and a.count(b"\n") == 1001
+
+
+def test_resume_state_continues_the_rule(amd, golden_dir, tmp_path):
+    """--save_resume (reference opal.py:310): train A then B in one run == train A, save the model WITH its accumulators
+    (version-2 container), load it into a fresh context, train_begin(resume=True), train B: bit-identical weights and
+    accumulators in the deterministic schedule.  A version-1 file (weights only) refuses to resume; resuming from weights
+    alone (accumulators restarted at zero) gives a different table, which is what the state is for."""
+    from opal_amd import model as model_io
+    rng = np.random.default_rng(21)
+    K, bits = 37, 18
+    pos = _patterns(amd, golden_dir, "patterns_k64_t16_m1_s7.txt", 64)
+    A = [bytes(rng.choice(ACGT, size=200)) for _ in range(300)]
+    B = [bytes(rng.choice(ACGT, size=200)) for _ in range(200)] + A[:50]
+    la = rng.integers(1, K + 1, size=len(A)).astype(np.int32)
+    lb = rng.integers(1, K + 1, size=len(B)).astype(np.int32)
+
+    def fresh():
+        e = amd.Engine(0)
+        e.set_patterns(pos, 64)
+        e.set_tuning(train_group=64)
+        return e
+
+    one = fresh()
+    one.train_begin(K, bits)
+    one.train_batch(one.upload(amd.PackedReads.from_sequences(A)), la, True, sequential=2)
+    path, path_v1 = str(tmp_path / "resumable.model"), str(tmp_path / "plain.model")
+    model_io.save_model(path, one.get_weights(), K, bits, g=one.get_accumulators(), batches=1)
+    model_io.save_model(path_v1, one.get_weights(), K, bits)
+    assert model_io.read_header(path)["resumable"] and model_io.read_header(path)["batches"] == 1
+    assert not model_io.read_header(path_v1)["resumable"]
+    assert os.path.getsize(path) > os.path.getsize(path_v1)
+    one.train_batch(one.upload(amd.PackedReads.from_sequences(B)), lb, True, sequential=2)
+    w_one, g_one = one.get_weights(to_host=True), one.get_accumulators().cpu().numpy()
+    one.close()
+
+    two = fresh()
+    model_io.load_model(path, two, resume=True)
+    two.train_begin(K, bits, resume=True)
+    two.train_batch(two.upload(amd.PackedReads.from_sequences(B)), lb, True, sequential=2)
+    assert np.array_equal(two.get_weights(to_host=True), w_one)
+    assert np.array_equal(two.get_accumulators().cpu().numpy(), g_one)
+    two.close()
+
+    three = fresh()
+    with pytest.raises(RuntimeError, match="no resume state"):
+        model_io.load_model(path_v1, three, resume=True)
+    model_io.load_model(path_v1, three)                      # weights only: the accumulators restart at zero
+    three.train_begin(K, bits, resume=True)
+    three.train_batch(three.upload(amd.PackedReads.from_sequences(B)), lb, True, sequential=2)
+    assert not np.array_equal(three.get_weights(to_host=True), w_one)
+    three.close()
