@@ -427,6 +427,146 @@ __global__ __launch_bounds__(BLOCK) void emit_canon2_kernel(Batch B, Geom G, uin
     emit_report_left(&s_left, left, lane, queue);
 }
 
+// ---- The canonical Opal geometry with numHash = 2 ... 8 (ldpc.py: pattern 0 a run of 16 positions, patterns 1 .. P-1 LDPC rows;
+// the reference CLI's default is --num-hash 8, P = 9: opal.py:534-536) gets the same treatment as numHash = 1: a step is
+// straight-line code over all P patterns (P is a template argument: no pattern loop, no per-pattern dispatch), the P hashes of a
+// window stay in registers and leave as ONE run of P consecutive dwords per lane (dwordx4 / dwordx2 / dword stores on dword
+// alignment) instead of P stores 4 P bytes apart, and the records of the LDPC rows stream through the scalar cache one pattern
+// ahead (17 SGPRs each: all P - 1 of them do not fit the scalar register file, so they are re-read every step; the scalar loads
+// travel with the previous pattern's gathers).  Pattern 0's one word rides with the first eight gathers of pattern 1 (zread9).
+typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u2u __attribute__((ext_vector_type(2), aligned(4)));
+struct PatRec { uint32_t q[16]; uint32_t tail; };
+__device__ __forceinline__ PatRec load_patrec(uint64_t fast_base, int p)
+{
+    // the base goes through an empty asm so that the loads below cannot be hoisted out of the step (and all records held at once)
+    asm volatile("" : "+s"(fast_base));
+    typedef const uint32_t __attribute__((address_space(4))) *const_u32;
+    const const_u32 fp = (const_u32)(uintptr_t)(fast_base + (uint64_t)p * (FASTPAT_DW * 4u));
+    PatRec r;
+#pragma unroll
+    for (int i = 0; i < 16; i++) r.q[i] = fp[i];
+    r.tail = fp[16];
+    return r;
+}
+template <int P, bool MIXED>
+__device__ __forceinline__ void canonP_step(uint32_t bf, uint32_t br, bool on_rc, uint64_t fast_base, uint32_t rq, uint32_t tail0, uint32_t u,
+                                            bool live, uint32_t mask, const uint32_t *tab, uint32_t *__restrict__ dst)
+{
+    const char *tabc = reinterpret_cast<const char *>(tab);
+    auto T = [&](uint32_t a) { return *reinterpret_cast<const uint32_t *>(tabc + a); };
+    auto rd8 = [&](const uint32_t (&q)[8], uint32_t (&x)[8]) {
+        zread8(bf, q, x);
+        if constexpr (MIXED) {
+            uint32_t y[8];
+            zread8(br, q, y);
+#pragma unroll
+            for (int i = 0; i < 8; i++) x[i] = on_rc ? y[i] : x[i];
+        }
+    };
+    uint32_t h[P];
+    PatRec rec = load_patrec(fast_base, 1);
+#pragma unroll
+    for (int p = 1; p < P; p++) {
+        PatRec nxt = rec;
+        if (p + 1 < P) nxt = load_patrec(fast_base, p + 1);        // in flight during this pattern's gathers
+        const uint32_t qa[8] = {rec.q[0], rec.q[1], rec.q[2], rec.q[3], rec.q[4], rec.q[5], rec.q[6], rec.q[7]};
+        const uint32_t qb[8] = {rec.q[8], rec.q[9], rec.q[10], rec.q[11], rec.q[12], rec.q[13], rec.q[14], rec.q[15]};
+        uint32_t x[8];
+        if (p == 1) {                                              // pattern 0's word travels with pattern 1's first half
+            uint32_t x0;
+            zread9(bf, rq, qa, x0, x);
+            if constexpr (MIXED) {
+                uint32_t y[8], y0;
+                zread9(br, rq, qa, y0, y);
+                x0 = on_rc ? y0 : x0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) x[i] = on_rc ? y[i] : x[i];
+            }
+            uint32_t a0[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) a0[b] = ((x0 >> (8 * b)) & 0xffu) << 2;
+            h[0] = mm_fmix(mm_hk(mm_hk(mm_hk(T(1024u + a0[0]), T(a0[1])), T(a0[2])), T(a0[3])) ^ tail0) & mask;
+        } else {
+            rd8(qa, x);
+        }
+        const uint32_t t0 = T(1024u + block_addr(x[0], x[1], x[2], x[3])), t1 = T(block_addr(x[4], x[5], x[6], x[7]));
+        rd8(qb, x);
+        const uint32_t t2 = T(block_addr(x[0], x[1], x[2], x[3])), t3 = T(block_addr(x[4], x[5], x[6], x[7]));
+        h[p] = mm_fmix(mm_hk(mm_hk(mm_hk(t0, t1), t2), t3) ^ rec.tail) & mask;
+        rec = nxt;
+    }
+    if (live) {                                                    // features u*P .. u*P+P-1: one run of P dwords
+        uint32_t *o = dst + u * (uint32_t)P;
+        int i = 0;
+#pragma unroll
+        for (; i + 4 <= P; i += 4) { u4u v; v.x = h[i]; v.y = h[i + 1]; v.z = h[i + 2]; v.w = h[i + 3]; *reinterpret_cast<u4u *>(o + i) = v; }
+        if (P - i >= 2) { u2u v; v.x = h[i]; v.y = h[i + 1]; *reinterpret_cast<u2u *>(o + i) = v; i += 2; }
+        if (P - i == 1) o[i] = h[i];
+    }
+}
+
+template <int P>
+__global__ __launch_bounds__(BLOCK) void emit_canonP_kernel(Batch B, Geom G, uint32_t mask, const uint64_t *__restrict__ out_off,
+                                                             uint32_t *__restrict__ out_idx, uint64_t out_cap,
+                                                             unsigned long long *__restrict__ queue, uint64_t qchunk)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_wave[WPB][2 * EF_ZLEN + 2 * EF_PKLEN];
+    __shared__ uint32_t s_tab[KTAB];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wv = threadIdx.x / WAVE;
+    __shared__ uint32_t s_left;   // fragments this block leaves to the generic kernel: ONE atomic per block at the end
+    if (threadIdx.x == 0) s_left = 0;
+    fill_kmer4_table(s_tab);
+    typedef const uint32_t __attribute__((address_space(4))) *const_u32;
+    const const_u32 f0 = (const_u32)(uintptr_t)G.fast;
+    const uint32_t rq = f0[18], tail0 = f0[16];
+    const uint64_t fast_base = (uint64_t)(uintptr_t)G.fast;
+    uint32_t *zw = s_wave[wv];
+    const uint32_t zfa = sgpr((uint32_t)(uintptr_t)zw), zra = zfa + EF_ZLEN * 4u;
+    const uint32_t S = G.reverse ? 2u : 1u;
+    uint32_t left = 0;
+    SubQ sq = subq_start(wv);
+    for (uint64_t q0 = first_chunk(wv, qchunk); q0 < B.n; q0 = next_chunk_subq(queue + Q_SUBQ_FAST, lane, qchunk, B.n, sq)) {
+        const uint64_t mine = q0 + (uint64_t)lane;
+        uint64_t o0 = 0, off = 0;
+        uint32_t lw = 0;
+        bool take = false, mine_left = false;
+        if ((uint64_t)lane < qchunk && mine < B.n) {
+            o0 = out_off[mine];
+            lw = B.len[mine];
+            off = B.off[mine];
+            const bool fits = !(o0 > out_cap || feature_count(lw, G) > out_cap - o0);   // never write outside out_idx
+            take = fits && emit_fast_takes(B, G, lw, off);
+            mine_left = fits && !take;
+        }
+        left += (uint32_t)__popcll(__ballot(mine_left));   // wave-uniform
+        uint64_t todo = __ballot(take);
+        EmitFetch nxt{0u, 0u};
+        if (todo) nxt = emit_fetch(B, readlane64(off, __builtin_ctzll(todo)), lane);
+        while (todo) {
+            const int i = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const EmitFetch cur = nxt;
+            if (todo) nxt = emit_fetch(B, readlane64(off, __builtin_ctzll(todo)), lane);   // in flight while fragment i is hashed
+            uint32_t *dst = out_idx + readlane64(o0, i);
+            const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)lw, i);
+            emit_stage(cur, G, readlane64(off, i), len, zw, lane);
+            const uint32_t W = len - (uint32_t)G.k + 1u, U = S * W;
+            for (uint32_t u0 = 0; u0 < U; u0 += WAVE) {
+                const uint32_t u = u0 + (uint32_t)lane;
+                const uint32_t bf = zfa + u0 * 4u, br = zra + (u0 - W) * 4u;
+                if (u0 + WAVE <= W || S == 1) canonP_step<P, false>(bf, 0u, false, fast_base, rq, tail0, u, u < U, mask, s_tab, dst);
+                else if (u0 >= W) canonP_step<P, false>(br, 0u, false, fast_base, rq, tail0, u, u < U, mask, s_tab, dst);
+                else canonP_step<P, true>(bf, br, u >= W, fast_base, rq, tail0, u, u < U, mask, s_tab, dst);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next fragment's staging stays behind these reads
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    emit_report_left(&s_left, left, lane, queue);
+}
+
 // The two emit kernels share one work loop: a wave draws qchunk (<= 64) consecutive fragments, every lane looks at one of
 // them (inside out_cap? the fast kernel's kind or the generic kernel's?), and the wave then walks the selected ones.
 // FAST = true: emit_fast for the fragments emit_fast_takes() accepts; counts the others in queue[2].
@@ -965,6 +1105,7 @@ extern "C" int opal_set_patterns(opal_ctx *ctx, const int32_t *pos, int P, int t
         OPAL_HIP_CHECK(ctx, hipMemcpy(ctx->d_fast, fp.data(), fp.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     ctx->fast_canon2 = fast_ok && P == 2 && canon2;
+    ctx->fast_canonP = fast_ok && P >= 3 && P <= 9 && canon2;   // a run followed by P - 1 gathered rows: emit_canonP_kernel<P>
     ctx->P = P; ctx->t = t; ctx->k = k;
     ctx->p0_run = pos[0];   // pattern 0 as a run of consecutive positions (Opal's first row: ldpc.py:83-85), else -1
     for (int j = 1; j < t; j++)
@@ -1174,6 +1315,16 @@ extern "C" int opal_features(opal_ctx *ctx, const uint8_t *d_reads, uint64_t rea
             if (rc) return rc;
             hipLaunchKernelGGL(emit_canon2_kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, B, G, mask, d_out_off, d_out_idx, out_cap,
                                ctx->d_queue, draw_for(grid));
+        } else if (ctx->fast_canonP) {
+            const void *fnP = ctx->P == 3 ? (const void *)&emit_canonP_kernel<3> : ctx->P == 4 ? (const void *)&emit_canonP_kernel<4>
+                            : ctx->P == 5 ? (const void *)&emit_canonP_kernel<5> : ctx->P == 6 ? (const void *)&emit_canonP_kernel<6>
+                            : ctx->P == 7 ? (const void *)&emit_canonP_kernel<7> : ctx->P == 8 ? (const void *)&emit_canonP_kernel<8>
+                                                                                                : (const void *)&emit_canonP_kernel<9>;
+            rc = grid_for(ctx, fnP, n, &grid);
+            if (rc) return rc;
+            uint64_t qc = draw_for(grid);
+            void *args[] = {&B, &G, (void *)&mask, &d_out_off, &d_out_idx, &out_cap, &ctx->d_queue, &qc};
+            OPAL_HIP_CHECK(ctx, hipLaunchKernel(fnP, dim3(grid), dim3(BLOCK), args, 0, ctx->stream));
         } else {
             rc = grid_for(ctx, (const void *)&emit_idx_kernel<true>, n, &grid);
             if (rc) return rc;
