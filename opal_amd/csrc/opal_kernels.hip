@@ -335,13 +335,16 @@ __device__ __forceinline__ void canon2_step(uint32_t bf, uint32_t br, bool on_rc
     uint32_t x[8], x0;
     const uint32_t qa[8] = {q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7]};
     const uint32_t qb[8] = {q[8], q[9], q[10], q[11], q[12], q[13], q[14], q[15]};
-    zread9(bf, rq, qa, x0, x);
+    // MIXED: every lane reads through its own address (its strand's array): one v_add per gather instead of reading both
+    // strands' arrays with add-TID reads and picking (the LDS is the unit this kernel is bound by, the VALU has slack)
+    const uint32_t vb = MIXED ? (on_rc ? br : bf) + 4u * (uint32_t)(threadIdx.x & (WAVE - 1)) : 0u;
+    auto vread = [&](uint32_t q) { return *reinterpret_cast<const uint32_t __attribute__((address_space(3))) *>((uintptr_t)(vb + q)); };
     if constexpr (MIXED) {
-        uint32_t y[8], y0;
-        zread9(br, rq, qa, y0, y);
-        x0 = on_rc ? y0 : x0;
+        x0 = vread(rq);
 #pragma unroll
-        for (int i = 0; i < 8; i++) x[i] = on_rc ? y[i] : x[i];
+        for (int i = 0; i < 8; i++) x[i] = vread(qa[i]);
+    } else {
+        zread9(bf, rq, qa, x0, x);
     }
     uint32_t a0[4], a1[4];
 #pragma unroll
@@ -350,12 +353,11 @@ __device__ __forceinline__ void canon2_step(uint32_t bf, uint32_t br, bool on_rc
     a1[1] = block_addr(x[4], x[5], x[6], x[7]);
     const uint32_t t00 = T(1024u + a0[0]), t01 = T(a0[1]), t02 = T(a0[2]), t03 = T(a0[3]);
     const uint32_t t10 = T(1024u + a1[0]), t11 = T(a1[1]);
-    zread8(bf, qb, x);
     if constexpr (MIXED) {
-        uint32_t y[8];
-        zread8(br, qb, y);
 #pragma unroll
-        for (int i = 0; i < 8; i++) x[i] = on_rc ? y[i] : x[i];
+        for (int i = 0; i < 8; i++) x[i] = vread(qb[i]);
+    } else {
+        zread8(bf, qb, x);
     }
     a1[2] = block_addr(x[0], x[1], x[2], x[3]);
     a1[3] = block_addr(x[4], x[5], x[6], x[7]);
@@ -455,13 +457,15 @@ __device__ __forceinline__ void canonP_step(uint32_t bf, uint32_t br, bool on_rc
 {
     const char *tabc = reinterpret_cast<const char *>(tab);
     auto T = [&](uint32_t a) { return *reinterpret_cast<const uint32_t *>(tabc + a); };
+    // MIXED: per-lane addresses into the lane's own strand (see canon2_step)
+    const uint32_t vb = MIXED ? (on_rc ? br : bf) + 4u * (uint32_t)(threadIdx.x & (WAVE - 1)) : 0u;
+    auto vread = [&](uint32_t q) { return *reinterpret_cast<const uint32_t __attribute__((address_space(3))) *>((uintptr_t)(vb + q)); };
     auto rd8 = [&](const uint32_t (&q)[8], uint32_t (&x)[8]) {
-        zread8(bf, q, x);
         if constexpr (MIXED) {
-            uint32_t y[8];
-            zread8(br, q, y);
 #pragma unroll
-            for (int i = 0; i < 8; i++) x[i] = on_rc ? y[i] : x[i];
+            for (int i = 0; i < 8; i++) x[i] = vread(q[i]);
+        } else {
+            zread8(bf, q, x);
         }
     };
     uint32_t h[P];
@@ -475,13 +479,11 @@ __device__ __forceinline__ void canonP_step(uint32_t bf, uint32_t br, bool on_rc
         uint32_t x[8];
         if (p == 1) {                                              // pattern 0's word travels with pattern 1's first half
             uint32_t x0;
-            zread9(bf, rq, qa, x0, x);
             if constexpr (MIXED) {
-                uint32_t y[8], y0;
-                zread9(br, rq, qa, y0, y);
-                x0 = on_rc ? y0 : x0;
-#pragma unroll
-                for (int i = 0; i < 8; i++) x[i] = on_rc ? y[i] : x[i];
+                x0 = vread(rq);
+                rd8(qa, x);
+            } else {
+                zread9(bf, rq, qa, x0, x);
             }
             uint32_t a0[4];
 #pragma unroll
