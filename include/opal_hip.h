@@ -63,7 +63,9 @@ int opal_set_patterns(opal_ctx *ctx, const int32_t *pos, int P, int t, int k);
 /* Replaces `vw -t -i <model>` loading its regressor (opal.py:449-451).  w is the compact table of the
  * 2^bits `w` components (one float per VW weight slot), K the --oaa class count (opal.py:311).  The ctx keeps
  * a private device copy padded by K floats so that rows never wrap.  opal_load_weights takes a HOST table,
- * opal_set_weights_device a DEVICE table (copied device-to-device).                                          */
+ * opal_set_weights_device a DEVICE table (copied device-to-device).  K is the number of distinct taxids
+ * (opal.py:288) and may be any value in 1 .. 2^20: rows start at slot (h*K) mod 2^bits, i.e. at any slot when K is
+ * odd, and are read with 16-byte loads on 4-byte alignment (no slow path for K that is not a multiple of 4).    */
 int opal_load_weights(opal_ctx *ctx, const float *w, uint64_t n_slots, int K, int bits);
 int opal_set_weights_device(opal_ctx *ctx, const float *d_w, uint64_t n_slots, int K, int bits);
 

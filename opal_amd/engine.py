@@ -401,9 +401,15 @@ class Engine:
                 return self.upload(PackedReads.from_sequences([]))
             d_text = t.from_numpy(arr.copy() if not arr.flags.writeable else arr).to(self.device)
         # the call reads the text once and needs no sizes in advance: buffers for records of >= 96 bytes of text each and
-        # for a few raw records first; a call that finds them too small reports what the text needs (OPAL_ERANGE)
+        # for a few raw records first; a call that finds them too small reports what the text needs (OPAL_ERANGE).  So that a
+        # large file of unusually short records is not read twice, the first guess follows the header density of the text's
+        # first MiB (one small copy to the host; a retry stays the safety net for texts whose start is not typical)
         nrec, nb = C.c_uint64(), C.c_uint64()
         max_rec, cap = n // 96 + 1024, n // 4 + n // 32 + 4096
+        if n >= (64 << 20):
+            head = d_text[:1 << 20].cpu().numpy()
+            headers = int(np.count_nonzero((head[1:] == 62) & ((head[:-1] == 10) | (head[:-1] == 13)))) + int(head[0] == 62)
+            max_rec = max(max_rec, int(headers * (n / head.size) * 1.25) + 1024)
         for _ in range(3):
             off = t.empty(max_rec, dtype=t.int64, device=self.device)
             ln = t.empty(max_rec, dtype=t.int32, device=self.device)
