@@ -8,11 +8,11 @@ for d in gpurun_out/prof_${T}_*; do
   t=${d#gpurun_out/prof_}
   o=profiles/$t
   mkdir -p $o
-  cp $d/kt/*/*_kernel_stats.csv $o/kernel_stats.csv
+  cp $(ls -t $d/kt/*/*_kernel_stats.csv | head -1) $o/kernel_stats.csv      # (gpurun_out/ keeps earlier calls' files: the newest)
   cp $d/summary.txt $o/summary.txt
   if [ -d $d/fetch ]; then
-    cp $d/fetch/*/*_counter_collection.csv $o/fetch_counter_collection.csv
-    cp $d/write/*/*_counter_collection.csv $o/write_counter_collection.csv
+    cp $(ls -t $d/fetch/*/*_counter_collection.csv | head -1) $o/fetch_counter_collection.csv
+    cp $(ls -t $d/write/*/*_counter_collection.csv | head -1) $o/write_counter_collection.csv
   fi
 done
 [ -f gpurun_out/${T}_cfg5_sq_lds_salu_counters.txt ] && cp gpurun_out/${T}_cfg5_sq_lds_salu_counters.txt profiles/${T}_cfg5_emit/sq_lds_salu_counters.txt
