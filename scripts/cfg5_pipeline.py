@@ -16,7 +16,8 @@ from opal_amd.engine import DeviceBatch  # noqa: E402
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 1564
 GL = int(sys.argv[2]) if len(sys.argv) > 2 else 4_000_000
-L, SUB = 200, 8_000_000
+L = 200
+SUB = int(os.environ.get("OPAL_CFG5_SUB", "0")) or G * (GL // L + 1)     # fragments per emit launch: by default the whole batch in one
 eng = amd.Engine(0)
 dev = eng.device
 with open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "patterns_k64_t16_m1_s7.txt")) as f:
@@ -56,7 +57,7 @@ for s in range(0, n, SUB):
     offsets = eng.feature_offsets(sub, True)
     tot = int(offsets[-1].item())
     if idx is None:
-        idx = torch.empty(SUB * 548, dtype=torch.int32, device=dev)
+        idx = torch.empty(min(SUB, n) * 548, dtype=torch.int32, device=dev)
     def emit():
         check(lib().opal_features(eng._h, sub.data.data_ptr(), sub.nbytes, sub.off.data_ptr(), sub.len.data_ptr(), sub.n, 1, 31,
                                   offsets.data_ptr(), idx.data_ptr(), tot), eng._h)
