@@ -731,6 +731,47 @@ def test_run_patterns_and_unsorted_rows_against_oracle(amd, eng, oracle):
     eng.set_vw_options()
 
 
+@pytest.mark.parametrize("P", [3, 4, 5, 6, 7, 8, 9, 10])
+def test_straight_line_emit_kernels_for_every_pattern_count(amd, eng, oracle, P):
+    """emit_canonP_kernel<P> (numHash 2 .. 8: a run followed by P - 1 gathered rows; P = 10 falls to the general fast kernel):
+    fragments around every step boundary (windows per strand 1, 63, 64, 65, 127, 128, 129, 449), both strands and one, rows that
+    hold consecutive positions inside a block, views at every base phase of a packed genome (the P dwords a lane stores are
+    only dword aligned), text fragments in the same batch (they go to the generic kernel)."""
+    import torch
+    rng = np.random.default_rng(900 + P)
+    k = 64
+    rows = [np.arange(16) + int(rng.integers(0, 49))]
+    for _ in range(P - 1):
+        r = np.sort(rng.choice(k, size=16, replace=False))
+        if rng.random() < 0.5:                                   # a block of four consecutive positions inside a gathered row
+            b = int(rng.integers(0, 4))
+            lo = int(min(r[4 * b], k - 4))
+            cand = np.concatenate([r[:4 * b], np.arange(lo, lo + 4), r[4 * b + 4:]])
+            if len(np.unique(cand)) == 16 and np.all(np.diff(cand) > 0):
+                r = cand
+        rows.append(r)
+    pos = np.stack(rows).astype(np.int32)
+    eng.set_patterns(pos, k)
+    lens = [0, 63, 64, 126, 127, 128, 190, 191, 192, 193, 200, 255, 256, 257, 300, 511, 512, 513, 600]
+    seqs = [bytes(rng.choice(ACGT, size=L)) for L in lens] + [b"ACGTNacgt" * 30, bytes(rng.choice(ACGT, size=200)).lower()]
+    for reverse in (True, False):
+        batch = eng.upload(amd.PackedReads.from_sequences(seqs))
+        idx, off = eng.features(batch, reverse, 31)
+        oidx, ooff = oracle.features_batch(seqs, k, pos, reverse, 31)
+        assert np.array_equal(off.cpu().numpy().view(np.uint64), ooff), (P, reverse)
+        assert np.array_equal(_u32(idx), oidx), (P, reverse)
+    # views into one packed genome at every base phase (offset mod 16), fragments of 200 and 137 bases
+    genome = bytes(rng.choice(ACGT, size=5000))
+    gs = amd.GenomeSet(eng, amd.PackedReads.from_sequences([genome]))
+    starts = np.arange(0, 1600, 37, dtype=np.uint64)
+    for L in (200, 137):
+        views = gs.fragments(starts, np.zeros(len(starts), dtype=np.uint32), L)
+        idx, off = eng.features(views, True, 32)
+        want, _ = oracle.features_batch([genome[int(a):int(a) + L] for a in starts], k, pos, True, 32)
+        assert np.array_equal(_u32(idx), want), (P, L)
+    eng.sync()
+
+
 def test_emit_never_writes_past_out_cap(amd, eng, oracle, golden_dir):
     """out_cap of opal_features / opal_feature_names: fragments whose range passes it are skipped, everything
     before is written as usual, nothing lands beyond the capacity."""

@@ -53,3 +53,31 @@ def test_two_rank_shard_and_gather(tmp_path, oracle):
     out = str(tmp_path / "result.txt")
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert open(out).read() == "ok"
+
+
+def test_bench_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): the N ranks are started as CHILD processes of
+    torch.distributed.run, the driver's own command line, with the caller's arguments; with fewer GPUs than ranks (none
+    here) the rendezvous falls back to gloo.  Nothing in that path may initialise the GPU."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("OPAL_DIST_BACKEND", raising=False)
+    assert bench.launch_ranks(4) == 7                                       # the launcher's exit code comes back
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    at = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[at + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["OPAL_DIST_BACKEND"] == "gloo"                       # no GPU in this container: rehearsal mode
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
