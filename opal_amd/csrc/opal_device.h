@@ -29,6 +29,7 @@ struct Geom {
     int hash_all;
     int p0_run;   // >= 0: pattern 0 is the ascending run p0_run, p0_run+1, ... (Opal's first row is 0..t-1); -1 otherwise
     int fast_canon2 = 0;        // emit fast path: P == 2, pattern 0 a run of 16 positions, pattern 1 gathered
+    int fast_maxlen = 512;      // emit fast path: longest fragment (bases) the launched fast kernel stages (EF_MAXLEN unless an experiment lowers it)
     const uint32_t *fast = nullptr;   // emit fast path (t == 16, positions ascending inside every block of 4): FASTPAT_DW dwords per pattern, else nullptr
 };
 

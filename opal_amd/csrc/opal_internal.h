@@ -34,6 +34,7 @@ struct opal_ctx {
     uint64_t tune_qchunk = 0;
     uint64_t train_group = 0;     // examples per group of the deterministic trainer, 0 = default (8192)
     void *dtrain = nullptr;       // buffers of the deterministic trainer (opal_dtrain.hip), grown on demand
+    int tune_emit_kt = 0;         // experiment: 2 / 3 = emit_canon2_kernel with per-base term arrays for pattern 0
     bool tune_emit_fast = true;   // false: opal_features uses the generic kernel only (tests compare the two)
     // scratch for the offsets scan
     unsigned long long *d_queue = nullptr;   // work-queue counter of the predict kernel (allocated with the ctx)

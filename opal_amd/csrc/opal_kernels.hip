@@ -100,6 +100,29 @@ __device__ __forceinline__ void zread8(uint32_t base, const uint32_t (&q)[8], ui
                    "=&s"(t0), "=&s"(t1)
                  : "s"(base), "s"(q[0]), "s"(q[1]), "s"(q[2]), "s"(q[3]), "s"(q[4]), "s"(q[5]), "s"(q[6]), "s"(q[7]) : "memory", "scc", "m0");
 }
+// zread4 + zread8 in one batch (the KT experiment: pattern 0's four per-base terms with the first half of pattern 1's gathers)
+__device__ __forceinline__ void zread12(uint32_t base, const uint32_t (&k)[4], const uint32_t (&q)[8], uint32_t (&kx)[4], uint32_t (&x)[8])
+{
+    uint32_t t0, t1;
+    asm volatile("s_add_u32 %12, %14, %15\n\ts_mov_b32 m0, %12\n\t"
+                 "s_add_u32 %13, %14, %16\n\tds_read_addtid_b32 %0\n\ts_mov_b32 m0, %13\n\t"
+                 "s_add_u32 %12, %14, %17\n\tds_read_addtid_b32 %1\n\ts_mov_b32 m0, %12\n\t"
+                 "s_add_u32 %13, %14, %18\n\tds_read_addtid_b32 %2\n\ts_mov_b32 m0, %13\n\t"
+                 "s_add_u32 %12, %14, %19\n\tds_read_addtid_b32 %3\n\ts_mov_b32 m0, %12\n\t"
+                 "s_add_u32 %13, %14, %20\n\tds_read_addtid_b32 %4\n\ts_mov_b32 m0, %13\n\t"
+                 "s_add_u32 %12, %14, %21\n\tds_read_addtid_b32 %5\n\ts_mov_b32 m0, %12\n\t"
+                 "s_add_u32 %13, %14, %22\n\tds_read_addtid_b32 %6\n\ts_mov_b32 m0, %13\n\t"
+                 "s_add_u32 %12, %14, %23\n\tds_read_addtid_b32 %7\n\ts_mov_b32 m0, %12\n\t"
+                 "s_add_u32 %13, %14, %24\n\tds_read_addtid_b32 %8\n\ts_mov_b32 m0, %13\n\t"
+                 "s_add_u32 %12, %14, %25\n\tds_read_addtid_b32 %9\n\ts_mov_b32 m0, %12\n\t"
+                 "s_add_u32 %13, %14, %26\n\tds_read_addtid_b32 %10\n\ts_mov_b32 m0, %13\n\t"
+                 "s_nop 0\n\tds_read_addtid_b32 %11\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(kx[0]), "=&v"(kx[1]), "=&v"(kx[2]), "=&v"(kx[3]), "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]),
+                   "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]), "=&s"(t0), "=&s"(t1)
+                 : "s"(base), "s"(k[0]), "s"(k[1]), "s"(k[2]), "s"(k[3]), "s"(q[0]), "s"(q[1]), "s"(q[2]), "s"(q[3]), "s"(q[4]), "s"(q[5]),
+                   "s"(q[6]), "s"(q[7]) : "memory", "scc", "m0");
+}
 // zread1 + zread8 in one batch (the canonical two-pattern step: pattern 0's one word and the first half of pattern 1's gathers)
 __device__ __forceinline__ void zread9(uint32_t base, uint32_t r, const uint32_t (&q)[8], uint32_t &xr, uint32_t (&x)[8])
 {
@@ -226,9 +249,14 @@ __device__ __forceinline__ EmitFetch emit_fetch(const Batch &B, uint64_t off, in
 }
 
 // Stages one fragment (2-bit packed, len <= EF_MAXLEN, its dwords inside the buffer, fetched by emit_fetch) as the per-base arrays Z_f, Z_r.
-__device__ __forceinline__ void emit_stage(const EmitFetch &pf, const Geom &G, uint64_t off, uint32_t len, uint32_t *zw, int lane)
+// ZL: Z entries per strand (EF_ZLEN serves fragments of up to EF_MAXLEN bases).  KT (experiment): also KT[i] = the block table's
+// term of codes i .. i+3 for every base, behind the packed dwords, so that a run pattern reads its four terms per window with
+// add-TID reads instead of four conflicted table reads.
+template <int ZL = EF_ZLEN, bool KT = false>
+__device__ __forceinline__ void emit_stage(const EmitFetch &pf, const Geom &G, uint64_t off, uint32_t len, uint32_t *zw, int lane,
+                                           const uint32_t *tab = nullptr)
 {
-    uint32_t *zf = zw, *zr = zw + EF_ZLEN, *pkf = zw + 2 * EF_ZLEN, *pkr = pkf + EF_PKLEN;
+    uint32_t *zf = zw, *zr = zw + ZL, *pkf = zw + 2 * ZL, *pkr = pkf + EF_PKLEN;
     const uint32_t sh = (uint32_t)(off & 15u) * 2u;
     const uint32_t S = G.reverse ? 2u : 1u;
     // the fragment's bases as packed dwords behind one zero dword: base 0 of the fragment at bit 0 of pkf[1]
@@ -258,11 +286,19 @@ __device__ __forceinline__ void emit_stage(const EmitFetch &pf, const Geom &G, u
         const uint32_t bo = 2u * (uint32_t)lane + 30u, b = bo & 31u;
         const uint32_t *pff = pkf + (bo >> 5), *pr = pkr + (bo >> 5);
         uint32_t *zfl = zf + lane, *zrl = zr + lane;
+        uint32_t *kfl = pkr + EF_PKLEN + lane, *krl = kfl + ZL;
+        const char *tabc = reinterpret_cast<const char *>(tab);
 #pragma unroll
-        for (int it = 0; it < EF_MAXLEN / WAVE + 1; it++) {
+        for (int it = 0; it < (ZL - WAVE) / WAVE + 1; it++) {
             if ((uint32_t)(it * WAVE) > len) break;
-            zfl[it * WAVE] = __builtin_amdgcn_alignbit(pff[4 * it + 1], pff[4 * it], b);
-            if (S == 2) zrl[it * WAVE] = __builtin_amdgcn_alignbit(pr[4 * it + 1], pr[4 * it], b);
+            const uint32_t vf = __builtin_amdgcn_alignbit(pff[4 * it + 1], pff[4 * it], b);
+            zfl[it * WAVE] = vf;
+            if constexpr (KT) kfl[it * WAVE] = *reinterpret_cast<const uint32_t *>(tabc + (vf & 0x3fcu));   // bits 2..9 = codes i .. i+3
+            if (S == 2) {
+                const uint32_t vr = __builtin_amdgcn_alignbit(pr[4 * it + 1], pr[4 * it], b);
+                zrl[it * WAVE] = vr;
+                if constexpr (KT) krl[it * WAVE] = *reinterpret_cast<const uint32_t *>(tabc + (vr & 0x3fcu));
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -295,7 +331,7 @@ __device__ __forceinline__ bool emit_fast_takes(const Batch &B, const Geom &G, u
 {
     // (off <= 4 * reads_bytes first: an offset near 2^64 must not wrap the sums below and slip through; locate_fragment
     // rejects it, so such a fragment goes to the generic kernel and is reported by opal_sync)
-    return !(lw & OPAL_RAW_FLAG) && lw >= (uint32_t)G.k && lw <= (uint32_t)EF_MAXLEN && off <= (B.reads_bytes << 2) &&
+    return !(lw & OPAL_RAW_FLAG) && lw >= (uint32_t)G.k && lw <= (uint32_t)G.fast_maxlen && off <= (B.reads_bytes << 2) &&
            ((off + lw + 3) >> 2) <= B.reads_bytes && ((off + lw + 15) >> 4) <= (B.reads_bytes >> 2);
 }
 __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l)
@@ -319,10 +355,10 @@ __device__ __forceinline__ void emit_report_left(uint32_t *s_left, uint32_t left
 // is straight-line code (no pattern loop, no per-pattern dispatch), and the LDS round trips of the two patterns overlap:
 // pattern 0's word travels with the first half of pattern 1's gathers, the first six table reads with the second half.
 // MIXED: the one step per fragment whose lanes straddle the two strands reads both and picks per lane.
-template <bool MIXED>
+template <bool MIXED, bool KT = false>
 __device__ __forceinline__ void canon2_step(uint32_t bf, uint32_t br, bool on_rc, uint32_t rq, const uint32_t (&q)[16], uint32_t tail0,
                                             uint32_t tail1, uint32_t u, bool live, uint32_t mask, const uint32_t *tab,
-                                            uint32_t *__restrict__ dst)
+                                            uint32_t *__restrict__ dst, uint32_t ktoff = 0u)
 {
     const char *tabc = reinterpret_cast<const char *>(tab);
     // (tried: pattern 1's four lookups from a copy of the table in global memory, through the otherwise idle L1, to take
@@ -339,19 +375,35 @@ __device__ __forceinline__ void canon2_step(uint32_t bf, uint32_t br, bool on_rc
     // strands' arrays with add-TID reads and picking (the LDS is the unit this kernel is bound by, the VALU has slack)
     const uint32_t vb = MIXED ? (on_rc ? br : bf) + 4u * (uint32_t)(threadIdx.x & (WAVE - 1)) : 0u;
     auto vread = [&](uint32_t q) { return *reinterpret_cast<const uint32_t __attribute__((address_space(3))) *>((uintptr_t)(vb + q)); };
-    if constexpr (MIXED) {
-        x0 = vread(rq);
-#pragma unroll
-        for (int i = 0; i < 8; i++) x[i] = vread(qa[i]);
-    } else {
-        zread9(bf, rq, qa, x0, x);
-    }
     uint32_t a0[4], a1[4];
+    uint32_t t00, t01, t02, t03;
+    if constexpr (KT) {
+        // pattern 0's terms are per-base: window w's block b is base w + r + 4b: KT[w + r + 4b] (rq = 4 (r + 1))
+        const uint32_t kq[4] = {ktoff + rq - 4u, ktoff + rq + 12u, ktoff + rq + 28u, ktoff + rq + 44u};
+        uint32_t kx[4];
+        if constexpr (MIXED) {
 #pragma unroll
-    for (int b = 0; b < 4; b++) a0[b] = ((x0 >> (8 * b)) & 0xffu) << 2;
+            for (int i = 0; i < 4; i++) kx[i] = vread(kq[i]);
+#pragma unroll
+            for (int i = 0; i < 8; i++) x[i] = vread(qa[i]);
+        } else {
+            zread12(bf, kq, qa, kx, x);
+        }
+        t00 = mm_hk(0u, kx[0]); t01 = kx[1]; t02 = kx[2]; t03 = kx[3];
+    } else {
+        if constexpr (MIXED) {
+            x0 = vread(rq);
+#pragma unroll
+            for (int i = 0; i < 8; i++) x[i] = vread(qa[i]);
+        } else {
+            zread9(bf, rq, qa, x0, x);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; b++) a0[b] = ((x0 >> (8 * b)) & 0xffu) << 2;
+    }
     a1[0] = block_addr(x[0], x[1], x[2], x[3]);
     a1[1] = block_addr(x[4], x[5], x[6], x[7]);
-    const uint32_t t00 = T(1024u + a0[0]), t01 = T(a0[1]), t02 = T(a0[2]), t03 = T(a0[3]);
+    if constexpr (!KT) { t00 = T(1024u + a0[0]); t01 = T(a0[1]); t02 = T(a0[2]); t03 = T(a0[3]); }
     const uint32_t t10 = T(1024u + a1[0]), t11 = T(a1[1]);
     if constexpr (MIXED) {
 #pragma unroll
@@ -367,11 +419,13 @@ __device__ __forceinline__ void canon2_step(uint32_t bf, uint32_t br, bool on_rc
     if (live) *reinterpret_cast<uint2 *>(dst + 2u * u) = make_uint2(h0, h1);
 }
 
+template <bool KT, int ZL>
 __global__ __launch_bounds__(BLOCK) void emit_canon2_kernel(Batch B, Geom G, uint32_t mask, const uint64_t *__restrict__ out_off,
                                                              uint32_t *__restrict__ out_idx, uint64_t out_cap,
                                                              unsigned long long *__restrict__ queue, uint64_t qchunk)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_wave[WPB][2 * EF_ZLEN + 2 * EF_PKLEN];
+    __shared__ __attribute__((aligned(16))) uint32_t s_wave[WPB][(KT ? 4 : 2) * ZL + 2 * EF_PKLEN];
+    constexpr uint32_t KTOFF = (2u * ZL + 2u * EF_PKLEN) * 4u;     // KT_f - Z_f = KT_r - Z_r, in bytes
     __shared__ uint32_t s_tab[KTAB];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = threadIdx.x / WAVE;
@@ -385,7 +439,7 @@ __global__ __launch_bounds__(BLOCK) void emit_canon2_kernel(Batch B, Geom G, uin
     for (int i = 0; i < 16; i++) q[i] = f1[i];
     const uint32_t rq = f0[18], tail0 = f0[16], tail1 = f1[16];
     uint32_t *zw = s_wave[wv];
-    const uint32_t zfa = sgpr((uint32_t)(uintptr_t)zw), zra = zfa + EF_ZLEN * 4u;
+    const uint32_t zfa = sgpr((uint32_t)(uintptr_t)zw), zra = zfa + ZL * 4u;
     const uint32_t S = G.reverse ? 2u : 1u;
     uint32_t left = 0;
     SubQ sq = subq_start(wv);
@@ -413,14 +467,14 @@ __global__ __launch_bounds__(BLOCK) void emit_canon2_kernel(Batch B, Geom G, uin
             if (todo) nxt = emit_fetch(B, readlane64(off, __builtin_ctzll(todo)), lane);   // in flight while fragment i is hashed
             uint32_t *dst = out_idx + readlane64(o0, i);
             const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)lw, i);
-            emit_stage(cur, G, readlane64(off, i), len, zw, lane);
+            emit_stage<ZL, KT>(cur, G, readlane64(off, i), len, zw, lane, s_tab);
             const uint32_t W = len - (uint32_t)G.k + 1u, U = S * W;
             for (uint32_t u0 = 0; u0 < U; u0 += WAVE) {
                 const uint32_t u = u0 + (uint32_t)lane;
                 const uint32_t bf = zfa + u0 * 4u, br = zra + (u0 - W) * 4u;
-                if (u0 + WAVE <= W || S == 1) canon2_step<false>(bf, 0u, false, rq, q, tail0, tail1, u, u < U, mask, s_tab, dst);
-                else if (u0 >= W) canon2_step<false>(br, 0u, false, rq, q, tail0, tail1, u, u < U, mask, s_tab, dst);
-                else canon2_step<true>(bf, br, u >= W, rq, q, tail0, tail1, u, u < U, mask, s_tab, dst);
+                if (u0 + WAVE <= W || S == 1) canon2_step<false, KT>(bf, 0u, false, rq, q, tail0, tail1, u, u < U, mask, s_tab, dst, KTOFF);
+                else if (u0 >= W) canon2_step<false, KT>(br, 0u, false, rq, q, tail0, tail1, u, u < U, mask, s_tab, dst, KTOFF);
+                else canon2_step<true, KT>(bf, br, u >= W, rq, q, tail0, tail1, u, u < U, mask, s_tab, dst, KTOFF);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next fragment's staging stays behind these reads
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1189,6 +1243,7 @@ extern "C" int opal_set_tuning(opal_ctx *ctx, int predict_nt, uint64_t emit_qchu
     ctx->tune_nt = predict_nt;
     ctx->tune_qchunk = emit_qchunk;
     ctx->tune_emit_fast = emit_fast != 0;
+    ctx->tune_emit_kt = emit_fast >= 2 ? emit_fast : 0;
     ctx->train_group = train_group;
     return OPAL_OK;
 }
@@ -1311,12 +1366,19 @@ extern "C" int opal_features(opal_ctx *ctx, const uint8_t *d_reads, uint64_t rea
     if (fast) {
         G.fast = ctx->d_fast;
         G.fast_canon2 = ctx->fast_canon2;
+        static_assert(EF_MAXLEN == 512, "Geom::fast_maxlen's default");
+        if (ctx->tune_emit_kt == 2 && ctx->fast_canon2 && (reinterpret_cast<uintptr_t>(d_out_idx) & 7u) == 0) G.fast_maxlen = 256;
         // P == 2 makes every fragment's feature count even: with an 8-byte aligned d_out_idx every fragment's range is too
         if (ctx->fast_canon2 && (reinterpret_cast<uintptr_t>(d_out_idx) & 7u) == 0) {
-            rc = grid_for(ctx, (const void *)&emit_canon2_kernel, n, &grid);
+            // tune_emit_kt (experiment, opal_set_tuning emit_fast = 2 / 3): per-base term arrays for pattern 0, for fragments of up
+            // to 256 bases (2) or EF_MAXLEN (3); what such a kernel does not take goes to the generic kernel
+            const void *fn2 = ctx->tune_emit_kt == 2 ? (const void *)&emit_canon2_kernel<true, 320>
+                            : ctx->tune_emit_kt == 3 ? (const void *)&emit_canon2_kernel<true, EF_ZLEN> : (const void *)&emit_canon2_kernel<false, EF_ZLEN>;
+            rc = grid_for(ctx, fn2, n, &grid);
             if (rc) return rc;
-            hipLaunchKernelGGL(emit_canon2_kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, B, G, mask, d_out_off, d_out_idx, out_cap,
-                               ctx->d_queue, draw_for(grid));
+            uint64_t qc = draw_for(grid);
+            void *args[] = {&B, &G, (void *)&mask, &d_out_off, &d_out_idx, &out_cap, &ctx->d_queue, &qc};
+            OPAL_HIP_CHECK(ctx, hipLaunchKernel(fn2, dim3(grid), dim3(BLOCK), args, 0, ctx->stream));
         } else if (ctx->fast_canonP) {
             const void *fnP = ctx->P == 3 ? (const void *)&emit_canonP_kernel<3> : ctx->P == 4 ? (const void *)&emit_canonP_kernel<4>
                             : ctx->P == 5 ? (const void *)&emit_canonP_kernel<5> : ctx->P == 6 ? (const void *)&emit_canonP_kernel<6>

@@ -21,7 +21,8 @@ import sys
 for L in ([int(a) for a in sys.argv[1:]] or [100, 200, 250, 300, 512, 600]):
     n = 800_000_000 // L * 2 // len(pos)
     batch = eng.upload(amd.PackedReads.from_codes(rng.integers(0, 4, size=(n, L), dtype=np.uint8)))
-    for fast in (True, False):
+    ref = None
+    for fast in ((True, 2, 3, False) if os.environ.get("OPAL_KT") else (True, False)):   # 2 / 3: the per-base-term experiment
         eng.set_tuning(emit_fast=fast)
         for _ in range(12):                      # the first dozen launches run below the settled clock
             idx, off = eng.features(batch, True, 31)
@@ -32,6 +33,9 @@ for L in ([int(a) for a in sys.argv[1:]] or [100, 200, 250, 300, 512, 600]):
             idx, off = eng.features(batch, True, 31)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 5
+        if ref is None:
+            ref = idx.clone()
+        assert torch.equal(ref, idx), (L, fast)
         print("L=%3d fast=%-5s %6.2f ms  %7.1f M fragments/s  %6.1f G hashes/s" % (L, fast, dt * 1e3, n / dt / 1e6, idx.numel() / dt / 1e9), flush=True)
         del idx, off
 eng.set_tuning()

@@ -772,6 +772,26 @@ def test_straight_line_emit_kernels_for_every_pattern_count(amd, eng, oracle, P)
     eng.sync()
 
 
+def test_per_base_term_experiment_matches_the_shipped_emit_kernel(amd, eng, golden_dir):
+    """opal_set_tuning(emit_fast = 2 | 3): emit_canon2_kernel with per-base term arrays for the run pattern ("Emit,
+    round 3": measured, not adopted).  Same indices as the default kernel, for lengths either side of its 256-base variant's
+    limit (longer fragments go to the generic kernel there)."""
+    import torch
+    rng = np.random.default_rng(77)
+    eng.set_patterns(_patterns(amd, golden_dir, "patterns_k64_t16_m1_s7.txt", 64), 64)
+    seqs = [bytes(rng.choice(ACGT, size=int(L))) for L in list(rng.integers(0, 600, size=300)) + [63, 64, 65, 255, 256, 257, 511, 512, 513]]
+    batch = eng.upload(amd.PackedReads.from_sequences(seqs))
+    for reverse in (True, False):
+        eng.set_tuning()
+        want, _ = eng.features(batch, reverse, 31)
+        for knob in (2, 3):
+            eng.set_tuning(emit_fast=knob)
+            got, _ = eng.features(batch, reverse, 31)
+            assert torch.equal(got, want), (knob, reverse)
+    eng.set_tuning()
+    eng.sync()
+
+
 def test_emit_never_writes_past_out_cap(amd, eng, oracle, golden_dir):
     """out_cap of opal_features / opal_feature_names: fragments whose range passes it are skipped, everything
     before is written as usual, nothing lands beyond the capacity."""
