@@ -78,8 +78,9 @@ int opal_adopt_weights_device(opal_ctx *ctx, float *d_w, uint64_t n_slots, uint6
 /* Tuning knobs for tests and experiments (the defaults are the production settings; the library reads no environment
  * variables).  predict_nt: -1 = row-load cache policy by table size (non-temporal from 4 GiB), 0 = default loads,
  * 1 = non-temporal loads.  emit_qchunk: fragments per work-queue draw of opal_features (at most 64), 0 = default (32).
- * emit_fast: 1 = opal_features hashes short 2-bit packed fragments with its fast kernel (default), 0 = generic kernel only.
- * train_group: examples per group of opal_train_batch's deterministic mode, 0 = default (8192).                        */
+ * emit_fast: 1 = opal_features hashes short 2-bit packed fragments with its fast kernel (default), 0 = generic kernel only;
+ * 2 / 3 = a measured, not adopted experiment (per-base term arrays for the run pattern, fragments of up to 256 / 512 bases;
+ * canonical two-pattern geometry only, same output).  train_group: examples per group of opal_train_batch's deterministic mode, 0 = default (8192).                        */
 int opal_set_tuning(opal_ctx *ctx, int predict_nt, uint64_t emit_qchunk, int emit_fast, uint64_t train_group);
 
 /* VW behaviours that differ between versions, defaults in brackets:
@@ -172,7 +173,8 @@ int opal_predict(opal_ctx *ctx, const uint8_t *d_reads, uint64_t reads_bytes, co
  * see opal_amd/csrc/opal_train.hip.  [VW-unpinned]                                                          */
 
 /* Allocates (resume=0: zeroed) the 2^bits weight table and its AdaGrad accumulators.  resume=1 keeps the weights
- * already loaded in the ctx (same K and bits), like continuing from a --save_resume model.                   */
+ * already loaded in the ctx (same K and bits), like continuing from a --save_resume model; the accumulators are kept
+ * too when opal_load_accumulators_sparse installed them (or an earlier training left them), else they restart at zero. */
 int opal_train_begin(opal_ctx *ctx, int K, int bits, int resume);
 
 /* One pass over a batch of labelled fragments, in the order given (the caller shuffles: opal.py:363).
