@@ -562,6 +562,8 @@ __device__ __forceinline__ void canonP_step(uint32_t bf, uint32_t br, bool on_rc
     }
 }
 
+// (tried: every step through per-lane addresses -- compiler-scheduled ds_read_b32, one v_add per gather, no M0 traffic, finer
+// waits -- instead of the add-TID batches: 4-13 % slower at numHash 4 and 8)
 template <int P>
 __global__ __launch_bounds__(BLOCK) void emit_canonP_kernel(Batch B, Geom G, uint32_t mask, const uint64_t *__restrict__ out_off,
                                                              uint32_t *__restrict__ out_idx, uint64_t out_cap,

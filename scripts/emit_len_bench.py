@@ -22,7 +22,7 @@ for L in ([int(a) for a in sys.argv[1:]] or [100, 200, 250, 300, 512, 600]):
     n = 800_000_000 // L * 2 // len(pos)
     batch = eng.upload(amd.PackedReads.from_codes(rng.integers(0, 4, size=(n, L), dtype=np.uint8)))
     ref = None
-    for fast in ((True, 2, 3, False) if os.environ.get("OPAL_KT") else (True, False)):   # 2 / 3: the per-base-term experiment
+    for fast in (tuple(int(x) if x.isdigit() else x == "True" for x in os.environ["OPAL_KT"].split(",")) if os.environ.get("OPAL_KT") else (True, False)):   # 2 / 3: the per-base-term experiment
         eng.set_tuning(emit_fast=fast)
         for _ in range(12):                      # the first dozen launches run below the settled clock
             idx, off = eng.features(batch, True, 31)
