@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Benchmark of the Opal hot path on MI355X: fused fragment -> LDPC spaced-k-mer hashes -> OAA scores -> class.
 
-    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W            (N>1: one rank per GPU, launched by torch.distributed.run -- by the
+                                                              caller, or by this script itself when it finds no launcher)
 
 A "step" is one pass of the fused predict kernel over one batch of synthetic fragments that is already resident in
 HBM.  Headline workload (`value`, every N) = BASELINE.json configs[1]: 356 classes, 1M fragments of 200 bp per GPU,
@@ -13,7 +14,8 @@ JSON line (max over ranks, like the headline):
   cfg3_1564sp    configs[2]: K=1564, 12.5 M fragments per GPU = the per-GPU share of "100 M fragments over 8 GPUs"
                  (at --gpus 8 the ranks together score exactly that job in one step)
   cfg4_numhash4  configs[3]: K=1564, numHash=4 (P=5, F=1370)
-  cfg5_emit      configs[4]: training-feature generation (fragment views into HBM-resident genomes -> hashed features)
+  cfg5_emit      configs[4]: training-feature generation at its stated size: 1564 genomes x 4 Mbp resident in HBM, one batch at
+                 coverage 1 (31.28 M fragments drawn by the CPython-exact sampler as views, shuffled) -> hashed features, one launch
 Fragments are generated on the device from a seed (uniform ACGT: a 2-bit packed fragment is 50 random bytes), so set-up
 takes seconds at any size.
 
