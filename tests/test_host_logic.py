@@ -200,6 +200,9 @@ def test_model_container_roundtrip_on_cpu(tmp_path):
         def set_vw_options(self, *a):
             self.opts = a
 
+        def load_accumulators_sparse(self, idx, val):
+            self.acc = (np.array(idx), np.array(val))
+
     rng = np.random.default_rng(0)
     w = np.zeros(1 << 14, dtype=np.float32)
     nz = rng.choice(1 << 14, size=500, replace=False)
@@ -220,6 +223,30 @@ def test_model_container_roundtrip_on_cpu(tmp_path):
     model_io.save_model(p2, wd, 3, 10)
     e2 = FakeEngine()
     assert model_io.load_model(p2, e2)["dense"] and np.array_equal(e2.dense[0], wd)
+    # version 2 (`train --save-resume`): the same weights section, then the accumulators and the batch count; a version-1
+    # file and a file cut inside the resume section refuse to resume, and a plain load of a version-2 file ignores the section
+    g = np.zeros_like(w)
+    g[nz] = rng.random(500).astype(np.float32) + 0.5
+    p3 = str(tmp_path / "resumable_final.model")
+    model_io.save_model(p3, w, 7, 14, g=g, batches=3)
+    h3 = model_io.read_header(p3)
+    assert (h3["version"], h3["resumable"], h3["batches"], h3["nnz"]) == (2, True, 3, 500)
+    assert open(p3, "rb").read()[48:48 + 500 * 8] == open(p, "rb").read()[48:48 + 500 * 8]       # (48 = header size)
+    e3 = FakeEngine()
+    model_io.load_model(p3, e3, resume=True)
+    gi, gv = e3.acc
+    gback = np.zeros_like(g)
+    gback[gi] = gv
+    assert np.array_equal(gback, g) and np.array_equal(e3.sparse[0], idx)
+    e4 = FakeEngine()
+    model_io.load_model(p3, e4)
+    assert not hasattr(e4, "acc") and np.array_equal(e4.sparse[1], val)
+    with pytest.raises(RuntimeError, match="no resume state"):
+        model_io.load_model(p, FakeEngine(), resume=True)
+    cut = tmp_path / "cut_final.model"
+    cut.write_bytes(open(p3, "rb").read()[:-100])
+    with pytest.raises(RuntimeError, match="truncated"):
+        model_io.load_model(str(cut), FakeEngine(), resume=True)
     bad = tmp_path / "x_final.model"
     bad.write_bytes(b"\x06\x00\x00\x008.6.1\x00m")      # how a VW binary regressor starts
     with pytest.raises(RuntimeError):
