@@ -391,6 +391,30 @@ int alloc_floats(opal_ctx *ctx, float **p, uint64_t *cap, uint64_t need)
     return OPAL_OK;
 }
 
+// dst[idx[i]] = val[i] for nnz host pairs (dst: n_slots floats on the device, already zeroed on the ctx stream); synchronises.
+int scatter_pairs(opal_ctx *ctx, float *dst, const uint32_t *idx, const float *val, uint64_t nnz, const char *who)
+{
+    if (!nnz) return OPAL_OK;
+    struct Staging {   // released on every path
+        uint32_t *idx = nullptr;
+        float *val = nullptr;
+        ~Staging() { if (idx) (void)hipFree(idx); if (val) (void)hipFree(val); }
+    } stg;
+    hipError_t e = hipMalloc((void **)&stg.idx, nnz * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&stg.val, nnz * sizeof(float));
+    if (e != hipSuccess) return opal::fail(ctx, OPAL_ENOMEM, std::string(who) + ": hipMalloc failed: " + hipGetErrorString(e));
+    e = hipMemcpyAsync(stg.idx, idx, nnz * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(stg.val, val, nnz * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        const int grid = (int)std::min<uint64_t>((nnz + 255) / 256, 65536);
+        hipLaunchKernelGGL(scatter_weights_kernel, dim3(grid), dim3(256), 0, ctx->stream, dst, stg.idx, stg.val, nnz, ctx->n_slots);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return opal::fail(ctx, OPAL_EHIP, std::string(who) + ": " + hipGetErrorString(e));
+    return OPAL_OK;
+}
+
 }  // namespace
 
 extern "C" int opal_train_begin(opal_ctx *ctx, int K, int bits, int resume)
@@ -484,26 +508,8 @@ extern "C" int opal_load_weights_sparse(opal_ctx *ctx, const uint32_t *idx, cons
     if (rc) return rc;
     ctx->n_slots = n_slots; ctx->K = K; ctx->bits = bits; ctx->g2_valid = false;
     OPAL_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_w, 0, need * sizeof(float), ctx->stream));
-    if (nnz) {
-        // staging buffers are released on every path
-        struct Staging {
-            uint32_t *idx = nullptr;
-            float *val = nullptr;
-            ~Staging() { if (idx) (void)hipFree(idx); if (val) (void)hipFree(val); }
-        } stg;
-        hipError_t e = hipMalloc((void **)&stg.idx, nnz * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc((void **)&stg.val, nnz * sizeof(float));
-        if (e != hipSuccess) return opal::fail(ctx, OPAL_ENOMEM, std::string("opal_load_weights_sparse: hipMalloc failed: ") + hipGetErrorString(e));
-        e = hipMemcpyAsync(stg.idx, idx, nnz * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(stg.val, val, nnz * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) {
-            const int grid = (int)std::min<uint64_t>((nnz + 255) / 256, 65536);
-            hipLaunchKernelGGL(scatter_weights_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->d_w, stg.idx, stg.val, nnz, n_slots);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) return opal::fail(ctx, OPAL_EHIP, std::string("opal_load_weights_sparse: ") + hipGetErrorString(e));
-    }
+    rc = scatter_pairs(ctx, ctx->d_w, idx, val, nnz, "opal_load_weights_sparse");
+    if (rc) return rc;
     rc = refresh_mirror(ctx);
     if (rc) return rc;
     OPAL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -533,25 +539,8 @@ extern "C" int opal_load_accumulators_sparse(opal_ctx *ctx, const uint32_t *idx,
     if (rc) return rc;
     ctx->g2_valid = false;
     OPAL_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_g2, 0, ctx->n_slots * sizeof(float), ctx->stream));
-    if (nnz) {
-        struct Staging {
-            uint32_t *idx = nullptr;
-            float *val = nullptr;
-            ~Staging() { if (idx) (void)hipFree(idx); if (val) (void)hipFree(val); }
-        } stg;
-        hipError_t e = hipMalloc((void **)&stg.idx, nnz * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc((void **)&stg.val, nnz * sizeof(float));
-        if (e != hipSuccess) return opal::fail(ctx, OPAL_ENOMEM, std::string("opal_load_accumulators_sparse: hipMalloc failed: ") + hipGetErrorString(e));
-        e = hipMemcpyAsync(stg.idx, idx, nnz * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(stg.val, val, nnz * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) {
-            const int grid = (int)std::min<uint64_t>((nnz + 255) / 256, 65536);
-            hipLaunchKernelGGL(scatter_weights_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->d_g2, stg.idx, stg.val, nnz, ctx->n_slots);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) return opal::fail(ctx, OPAL_EHIP, std::string("opal_load_accumulators_sparse: ") + hipGetErrorString(e));
-    }
+    rc = scatter_pairs(ctx, ctx->d_g2, idx, val, nnz, "opal_load_accumulators_sparse");
+    if (rc) return rc;
     OPAL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->g2_valid = true;     // opal_train_begin(resume=1) keeps these accumulators
     return OPAL_OK;
