@@ -472,9 +472,12 @@ __global__ __launch_bounds__(BLOCK) void emit_canon2_kernel(Batch B, Geom G, uin
             for (uint32_t u0 = 0; u0 < U; u0 += WAVE) {
                 const uint32_t u = u0 + (uint32_t)lane;
                 const uint32_t bf = zfa + u0 * 4u, br = zra + (u0 - W) * 4u;
-                if (u0 + WAVE <= W || S == 1) canon2_step<false, KT>(bf, 0u, false, rq, q, tail0, tail1, u, u < U, mask, s_tab, dst, KTOFF);
-                else if (u0 >= W) canon2_step<false, KT>(br, 0u, false, rq, q, tail0, tail1, u, u < U, mask, s_tab, dst, KTOFF);
-                else canon2_step<true, KT>(bf, br, u >= W, rq, q, tail0, tail1, u, u < U, mask, s_tab, dst, KTOFF);
+                // the fragment's last step under EXEC = its live lanes only (18 of 64 at 200 bases): the LDS serves 32 lanes a
+                // pass and the table reads collide less with fewer lanes
+                if (u0 + WAVE > U && u >= U) continue;
+                if (u0 + WAVE <= W || S == 1) canon2_step<false, KT>(bf, 0u, false, rq, q, tail0, tail1, u, true, mask, s_tab, dst, KTOFF);
+                else if (u0 >= W) canon2_step<false, KT>(br, 0u, false, rq, q, tail0, tail1, u, true, mask, s_tab, dst, KTOFF);
+                else canon2_step<true, KT>(bf, br, u >= W, rq, q, tail0, tail1, u, true, mask, s_tab, dst, KTOFF);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next fragment's staging stays behind these reads
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -614,9 +617,10 @@ __global__ __launch_bounds__(BLOCK) void emit_canonP_kernel(Batch B, Geom G, uin
             for (uint32_t u0 = 0; u0 < U; u0 += WAVE) {
                 const uint32_t u = u0 + (uint32_t)lane;
                 const uint32_t bf = zfa + u0 * 4u, br = zra + (u0 - W) * 4u;
-                if (u0 + WAVE <= W || S == 1) canonP_step<P, false>(bf, 0u, false, fast_base, rq, tail0, u, u < U, mask, s_tab, dst);
-                else if (u0 >= W) canonP_step<P, false>(br, 0u, false, fast_base, rq, tail0, u, u < U, mask, s_tab, dst);
-                else canonP_step<P, true>(bf, br, u >= W, fast_base, rq, tail0, u, u < U, mask, s_tab, dst);
+                if (u0 + WAVE > U && u >= U) continue;         // the last step under EXEC = its live lanes (see emit_canon2_kernel)
+                if (u0 + WAVE <= W || S == 1) canonP_step<P, false>(bf, 0u, false, fast_base, rq, tail0, u, true, mask, s_tab, dst);
+                else if (u0 >= W) canonP_step<P, false>(br, 0u, false, fast_base, rq, tail0, u, true, mask, s_tab, dst);
+                else canonP_step<P, true>(bf, br, u >= W, fast_base, rq, tail0, u, true, mask, s_tab, dst);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next fragment's staging stays behind these reads
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
