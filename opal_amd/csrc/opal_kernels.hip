@@ -1451,7 +1451,7 @@ extern "C" int opal_predict(opal_ctx *ctx, const uint8_t *d_reads, uint64_t read
     const uint32_t mask = ctx->bits == 32 ? 0xffffffffu : ((1u << ctx->bits) - 1u);
     const uint32_t const_idx = OPAL_VW_CONSTANT & mask;
     const Variant &v = pick_variant(ctx->K);
-    // cache policy of the row loads by table size (see nt_load) unless opal_set_tuning forces one
+    // cache policy of the row loads by table size (see row_load) unless opal_set_tuning forces one
     const bool nt = ctx->tune_nt < 0 ? ctx->n_slots * sizeof(float) >= NT_TABLE_BYTES : ctx->tune_nt != 0;
     const void *fn = nt ? v.fn_nt : v.fn;
     int grid = 1;
