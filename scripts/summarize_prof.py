@@ -56,6 +56,32 @@ def main(out):
             if launches:
                 res[ctr + "_KiB_per_launch"] = tot / launches
                 res[ctr + "_launches"] = launches
+    if any("dtrain_" in n for n in stats):
+        # deterministic learner: several kernels per group; per kernel, mean counter values per dispatch against the mean
+        # duration of the kernel-trace run.  Reads are quoted both ways (raw, and x2 as for the wide row gathers); writes are
+        # exact, and since every row the apply kernels write they have also read, 2 x WRITE_SIZE is a floor for their traffic.
+        per = {}
+        for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+            for r in rows(os.path.join(out, sub, "**", "*counter_collection.csv")):
+                if r.get("Counter_Name") == ctr and "dtrain_" in r["Kernel_Name"]:
+                    short = r["Kernel_Name"].split("dtrain_")[1].split("(")[0]
+                    per.setdefault("dtrain_" + short, {}).setdefault(ctr, []).append(float(r["Counter_Value"]))
+        tab = {}
+        for n, r in stats.items():
+            if "dtrain_" not in n:
+                continue
+            short = "dtrain_" + n.split("dtrain_")[1].split("(")[0]
+            c = per.get(short, {})
+            if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+                continue
+            ms = float(r["AverageNs"]) / 1e6
+            f = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"]) * 1024
+            w = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"]) * 1024
+            tab[short] = {"calls": int(r["Calls"]), "avg_ms": ms, "fetch_bytes_raw": f, "write_bytes": w,
+                          "GBps_reads_x2_plus_writes": (2 * f + w) / ms / 1e6, "GBps_floor_2x_writes": 2 * w / ms / 1e6,
+                          "GBps_raw_reads_plus_writes": (f + w) / ms / 1e6}
+        if tab:
+            res["learner_kernels"] = tab
     if "FETCH_SIZE_KiB_per_launch" in res:
         rd = res["FETCH_SIZE_KiB_per_launch"] * 1024 * 2   # gfx950: wide coalesced reads are tallied at half
         wr = res.get("WRITE_SIZE_KiB_per_launch", 0.0) * 1024
