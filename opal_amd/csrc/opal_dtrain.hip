@@ -67,7 +67,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(NV >= 8 ?
                                                               const uint64_t *__restrict__ foff, float *__restrict__ upd_out,
                                                               float *__restrict__ gsq_out, float *__restrict__ sfac,
                                                               uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                                                              int32_t *__restrict__ out_pred, unsigned long long *__restrict__ queue)
+                                                              int32_t *__restrict__ out_pred, unsigned long long *__restrict__ queue,
+                                                              unsigned long long *__restrict__ amask, uint32_t nit)
 {
     using V = typename VecOf<VEC>::type;
     constexpr int CH = WAVE * VEC * NV;
@@ -216,6 +217,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(NV >= 8 ?
                     u[x] = v;
                     q[x] = gsq[j][x];
                 }
+                // which of the example's vectors carry a step: one bit per lane, one word per pass of phase B's row loop (same
+                // lane <-> class mapping there), so that phase B fetches the step arrays of live vectors only
+                {
+                    bool live = reg_on && cls[j] < Ku;
+#pragma unroll
+                    for (int x = 0; x < VEC; x++) live = live || (u[x] != 0.0f) || (q[x] != 0.0f);
+                    const unsigned long long m = __ballot(live);
+                    const uint32_t it = c0 / (uint32_t)(WAVE * VEC) + (uint32_t)j;
+                    if (lane == 0 && it < nit) amask[e * (uint64_t)nit + it] = m;
+                }
                 if (cls[j] + (uint32_t)VEC <= Ku) {
                     vstoreu<VEC>(upd_out + e * (uint64_t)Ku + cls[j], u);
                     vstoreu<VEC>(gsq_out + e * (uint64_t)Ku + cls[j], q);
@@ -262,7 +273,8 @@ __global__ __launch_bounds__(BLOCK) void dtrain_apply_kernel(float *__restrict__
                                                               const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                               const uint32_t *__restrict__ pstart, uint32_t NP, uint32_t colour,
                                                               const float *__restrict__ upd, const float *__restrict__ gsq,
-                                                              const float *__restrict__ sfac, DArgs ta, unsigned long long *__restrict__ queue)
+                                                              const float *__restrict__ sfac, DArgs ta, unsigned long long *__restrict__ queue,
+                                                              const unsigned long long *__restrict__ amask, uint32_t nit)
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = threadIdx.x / WAVE;
@@ -280,23 +292,24 @@ __global__ __launch_bounds__(BLOCK) void dtrain_apply_kernel(float *__restrict__
             const float s = sfac[e];
             const float decay = 1.0f - s * ta.l2, shrink = s * ta.l1;
             const float *ue = upd + (uint64_t)e * Ku, *qe = gsq + (uint64_t)e * Ku;
+            const unsigned long long *me = amask + (uint64_t)e * nit;
             // one row: G += q, w += u / sqrt(G) for the classes with a step.  The last vector of an example's steps may reach into the
             // next example's (the arrays are padded): the excess is zeroed.  A row that passes the table's end (wave-uniform, rare)
             // is worked slot by slot; a contiguous one with one vector load and store per table, the row's last vector, when partial,
             // stored slot by slot.
             auto one_row = [&](auto crossing) {
                 constexpr bool CROSS = decltype(crossing)::value;
-                for (uint32_t c = (uint32_t)lane * VEC; c < Ku; c += WAVE * VEC) {
+                for (uint32_t it = 0; it < nit; it++) {
+                    // classes already at their label: nothing to add (as VW skips zero updates).  Phase A left one bit per vector
+                    // (step != 0 or accumulator term != 0, or regularisation on): the step arrays of the others are not even fetched
+                    if (!((me[it] >> lane) & 1ull)) continue;
+                    const uint32_t c = (uint32_t)lane * VEC + it * (uint32_t)(WAVE * VEC);
                     float u[VEC], qv[VEC];
                     vloadu<VEC>(ue + c, u);
                     vloadu<VEC>(qe + c, qv);
-                    bool any = reg;
 #pragma unroll
-                    for (int x = 0; x < VEC; x++) {
+                    for (int x = 0; x < VEC; x++)
                         if (c + (uint32_t)x >= Ku) { u[x] = 0.0f; qv[x] = 0.0f; }
-                        any = any || (qv[x] != 0.0f) || (u[x] != 0.0f);
-                    }
-                    if (!any) continue;                          // classes already at their label: nothing to add (as VW skips zero updates)
                     float gv[VEC], wv[VEC];
                     row_vload<VEC, AL>(g2, row, c, Ku, mask, CROSS, true, gv);
                     row_vload<VEC, AL>(w, row, c, Ku, mask, CROSS, true, wv);
@@ -367,7 +380,9 @@ __global__ __launch_bounds__(256) void dtrain_const_kernel(float *__restrict__ w
             if (tile + 1 < ntile) load_tile(tile + 1, buf ^ 1);
         } else {
             // branch-free, eight examples at a time out of registers: the only serial dependences are one add for G and an
-            // add + select for w per example (with a branch per example every step paid the LDS and rsq latencies: 100 ns)
+            // add + select for w per example (with a branch per example every step paid the LDS and rsq latencies: 100 ns;
+            // walking only the examples that carry a step for these 64 classes, from a per-tile bit mask, doubled the kernel's
+            // time in round 3: the fixed loop lets the LDS reads of the next eight run ahead, a data-dependent one does not)
             const uint32_t cnt = min((uint32_t)CT, gn - tile * CT);
             for (uint32_t x0 = 0; x0 < cnt; x0 += 8) {
                 float u[8], q[8], sx[8];
@@ -428,6 +443,8 @@ struct DTrainState {
     uint64_t upd_cap = 0, gsq_cap = 0, sfac_cap = 0;
     uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *pstart = nullptr;
     uint64_t k_cap[2] = {0, 0}, v_cap[2] = {0, 0}, pstart_cap = 0;
+    unsigned long long *amask = nullptr;      // per example of the group, one 64-bit word per 64 vectors of classes: which carry a step
+    uint64_t amask_cap = 0;
     void *temp = nullptr;
     size_t temp_cap = 0;
 };
@@ -449,7 +466,7 @@ void opal::dtrain_free(opal_ctx *ctx)
 {
     DTrainState *st = static_cast<DTrainState *>(ctx->dtrain);
     if (!st) return;
-    void *all[] = {st->foff, st->bounds, st->upd, st->gsq, st->sfac, st->keys[0], st->keys[1], st->vals[0], st->vals[1], st->pstart, st->temp};
+    void *all[] = {st->foff, st->bounds, st->upd, st->gsq, st->sfac, st->keys[0], st->keys[1], st->vals[0], st->vals[1], st->pstart, st->amask, st->temp};
     for (void *p : all)
         if (p) (void)hipFree(p);
     delete st;
@@ -497,6 +514,10 @@ int opal::train_batch_groups(opal_ctx *ctx, const uint8_t *d_reads, uint64_t rea
     if (rc) return rc;
     rc = grow(ctx, &st->sfac, &st->sfac_cap, gmax);
     if (rc) return rc;
+    const int vec = K >= 4 ? 4 : (K % 2 == 0) ? 2 : 1;                     // 16-byte vectors for every K >= 4 (dword-aligned, see row_vload)
+    const uint32_t nit = (uint32_t)((K + WAVE * vec - 1) / (WAVE * vec));  // passes of 64 vectors over a row
+    rc = grow(ctx, &st->amask, &st->amask_cap, gmax * (uint64_t)nit);
+    if (rc) return rc;
     for (int i = 0; i < 2; i++) {
         rc = grow(ctx, &st->keys[i], &st->k_cap[i], max_keys);
         if (rc) return rc;
@@ -522,8 +543,7 @@ int opal::train_batch_groups(opal_ctx *ctx, const uint8_t *d_reads, uint64_t rea
     const uint32_t mask = ctx->bits == 32 ? 0xffffffffu : ((1u << ctx->bits) - 1u);
     const uint32_t const_idx = OPAL_VW_CONSTANT & mask;
     const uint32_t crow = (uint32_t)(((uint64_t)const_idx * (uint64_t)K) & mask);
-    const int vec = K >= 4 ? 4 : (K % 2 == 0) ? 2 : 1;                     // 16-byte vectors for every K >= 4 (dword-aligned, see row_vload)
-    const int need = (K + WAVE * vec - 1) / (WAVE * vec);
+    const int need = (int)nit;
     const int nv = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 8;
     const void *score_fn = kScoreVariants[0].fn;
     const bool al = K % vec == 0;
@@ -541,6 +561,8 @@ int opal::train_batch_groups(opal_ctx *ctx, const uint8_t *d_reads, uint64_t rea
     float *upd = st->upd, *gsq = st->gsq, *sfac = st->sfac;
     const uint64_t *foff = st->foff;
     unsigned long long *queue = ctx->d_queue;
+    unsigned long long *amask = st->amask;
+    const unsigned long long *camask = st->amask;
 
     for (uint64_t g = 0; g < ng; g++) {
         uint64_t e0 = g * gs;
@@ -552,7 +574,7 @@ int opal::train_batch_groups(opal_ctx *ctx, const uint8_t *d_reads, uint64_t rea
         {
             const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((gn + WPB - 1) / WPB, (uint64_t)ctx->num_cus * per_cu_s));
             void *args[] = {&B, &G, &w, &g2, (void *)&mask, (void *)&K, (void *)&const_idx, &d_labels, &ta, &e0, &gn, &foff, &upd, &gsq, &sfac,
-                            &keys_in, &vals_in, &d_out_pred, &queue};
+                            &keys_in, &vals_in, &d_out_pred, &queue, &amask, (void *)&nit};
             OPAL_HIP_CHECK(ctx, hipLaunchKernel(score_fn, dim3(grid), dim3(BLOCK), args, 0, ctx->stream));
         }
         if (nk) {
@@ -568,7 +590,7 @@ int opal::train_batch_groups(opal_ctx *ctx, const uint8_t *d_reads, uint64_t rea
                 const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((nq + WPB - 1) / WPB, (uint64_t)ctx->num_cus * per_cu_a));
                 const uint32_t *ks = keys_s, *vs = vals_s, *ps = st->pstart;
                 const float *cu = upd, *cq = gsq, *cs = sfac;
-                void *args[] = {&w, &g2, (void *)&mask, (void *)&K, &ks, &vs, &ps, (void *)&NP, &colour, &cu, &cq, &cs, &ta, &queue};
+                void *args[] = {&w, &g2, (void *)&mask, (void *)&K, &ks, &vs, &ps, (void *)&NP, &colour, &cu, &cq, &cs, &ta, &queue, &camask, (void *)&nit};
                 OPAL_HIP_CHECK(ctx, hipLaunchKernel(apply_fn, dim3(grid), dim3(BLOCK), args, 0, ctx->stream));
             }
         }
