@@ -338,8 +338,10 @@ __global__ __launch_bounds__(BLOCK) void dtrain_apply_kernel(float *__restrict__
 // loop waited 100 ns per example even with 32 examples' loads in flight (0.83 ms per group of 8192, a tenth of the
 // group's time and a fifth in later passes).  Here three waves of the block stream tiles of CT examples x 64 classes
 // into LDS, one tile ahead, and the fourth wave runs the chain out of LDS.  Same operations in the same order per class.
+// (Loads two tiles ahead, the registers riding through the barrier, changed nothing: the chain wave sets the pace.)
 constexpr int CT = 32;                 // examples per tile: 2 buffers x 2 arrays x 32 x 64 floats = 32 KiB of LDS
 constexpr int CT_LOADERS = 192;        // threads of waves 1-3
+template <bool REG>   // regularisation on (l1 or l2 non-zero): off, a step is one add and the chain half as long
 __global__ __launch_bounds__(256) void dtrain_const_kernel(float *__restrict__ w, float *__restrict__ g2, uint32_t mask, int K, uint32_t crow,
                                                             const float *__restrict__ upd, const float *__restrict__ gsq,
                                                             const float *__restrict__ sfac, uint32_t gn, DArgs ta)
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(256) void dtrain_const_kernel(float *__restrict__ w
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
     const uint32_t c0 = blockIdx.x * WAVE, c = c0 + (uint32_t)lane;
     const uint32_t Ku = (uint32_t)K;
-    const bool reg = (ta.l1 != 0.0f) || (ta.l2 != 0.0f);
+    constexpr bool reg = REG;
     const uint32_t ntile = (gn + CT - 1) / CT;
     auto load_tile = [&](uint32_t tile, int buf) {          // waves 1-3: all loads first, then the LDS stores
         constexpr int PER = (CT * WAVE + CT_LOADERS - 1) / CT_LOADERS;
@@ -393,7 +395,8 @@ __global__ __launch_bounds__(256) void dtrain_const_kernel(float *__restrict__ w
                 }
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
-                    const bool off = x0 + (uint32_t)k >= cnt || (!reg && q[k] == 0.0f && u[k] == 0.0f);   // a step that is skipped
+                    // a step that is skipped (bitwise on purpose: short-circuit evaluation became a branch per example)
+                    const bool off = (x0 + (uint32_t)k >= cnt) | (!reg & (q[k] == 0.0f) & (u[k] == 0.0f));
                     const float Gn = Gc + q[k];
                     const float d = (Gn > 0.0f) ? u[k] * rsq(Gn) : 0.0f;
                     const float Wn = step_w(Wc, d, reg, 1.0f - sx[k] * ta.l2, sx[k] * ta.l1);
@@ -595,8 +598,12 @@ int opal::train_batch_groups(opal_ctx *ctx, const uint8_t *d_reads, uint64_t rea
             }
         }
         // C: the constant row, examples in order
-        hipLaunchKernelGGL(dtrain_const_kernel, dim3((K + 63) / 64), dim3(256), 0, ctx->stream, w, g2, mask, K, crow, (const float *)upd,
-                           (const float *)gsq, (const float *)sfac, gn, ta);
+        if (l1 != 0.0f || l2 != 0.0f)
+            hipLaunchKernelGGL(dtrain_const_kernel<true>, dim3((K + 63) / 64), dim3(256), 0, ctx->stream, w, g2, mask, K, crow, (const float *)upd,
+                               (const float *)gsq, (const float *)sfac, gn, ta);
+        else
+            hipLaunchKernelGGL(dtrain_const_kernel<false>, dim3((K + 63) / 64), dim3(256), 0, ctx->stream, w, g2, mask, K, crow, (const float *)upd,
+                               (const float *)gsq, (const float *)sfac, gn, ta);
         OPAL_HIP_CHECK(ctx, hipGetLastError());
     }
     const uint32_t pad = (uint32_t)K + 4;
