@@ -572,8 +572,8 @@ def test_resume_state_continues_the_rule(amd, golden_dir, tmp_path):
     three.close()
 
 
-def test_deterministic_training_fuzz(amd, oracle, golden_dir):
-    """Seeded fuzz of opal_train_batch mode 2 against oracle.train_groups over what the kernels specialise on: the class count
+def test_training_fuzz(amd, oracle, golden_dir):
+    """Seeded fuzz of opal_train_batch mode 2 against oracle.train_groups (and, a third of the trials, mode 1 against oracle.train) over what the kernels specialise on: the class count
     (1 .. 40, and around every multiple of 256 = one pass of 64 lanes x 4 classes, up to 2 chunks of 2048), the table size
     (rows overlap and wrap on the small ones), the group size (1 .. 50: short last groups, groups of one), numHash 1 and 4,
     one or both strands, regularisation on and off, fragments of 0 .. 400 bases, some as text.  Two passes: the second starts
@@ -591,6 +591,7 @@ def test_deterministic_training_fuzz(amd, oracle, golden_dir):
         reverse = bool(rng.integers(0, 2))
         pos = pats[int(rng.integers(0, 2))]
         l1, l2 = ((1e-4, 1e-3) if rng.random() < 0.25 else (0.0, 0.0))
+        mode = 2 if rng.random() < 0.65 else 1        # 1: the one-wave sequential schedule (train_kernel) against oracle.train
         seqs = []
         for _ in range(int(rng.integers(1, 36))):
             L = int(rng.choice([0, 30, 63, 64, 65, 100, 200, 200, 200, 257, 400]))
@@ -605,10 +606,13 @@ def test_deterministic_training_fuzz(amd, oracle, golden_dir):
         w = np.zeros(1 << bits, dtype=np.float32)
         g2 = np.zeros(1 << bits, dtype=np.float32)
         pshift = oracle.train_pshift(K, bits)
-        what = dict(trial=trial, K=K, bits=bits, group=group, reverse=reverse, P=int(pos.shape[0]), l1=l1, n=len(seqs))
+        what = dict(trial=trial, mode=mode, K=K, bits=bits, group=group, reverse=reverse, P=int(pos.shape[0]), l1=l1, n=len(seqs))
         for p in range(2):
-            eng.train_batch(batch, labels, reverse, eta=0.5, l1=l1, l2=l2, sequential=2)
-            oracle.train_groups(seqs, labels, 64, pos, reverse, w, g2, K, bits, group, pshift, eta=0.5, l1=l1, l2=l2)
+            eng.train_batch(batch, labels, reverse, eta=0.5, l1=l1, l2=l2, sequential=mode)
+            if mode == 2:
+                oracle.train_groups(seqs, labels, 64, pos, reverse, w, g2, K, bits, group, pshift, eta=0.5, l1=l1, l2=l2)
+            else:
+                oracle.train(seqs, labels, 64, pos, reverse, w, g2, K, bits, eta=0.5, l1=l1, l2=l2)
             gw = eng.get_weights(to_host=True)
             gg = eng.get_accumulators().cpu().numpy()
             # GPU expf / v_rsq_f32 against libm, through as many steps as a slot takes: on the small tables here a slot belongs to
@@ -621,4 +625,4 @@ def test_deterministic_training_fuzz(amd, oracle, golden_dir):
             if nz.any():
                 worst = max(worst, float((np.abs(gw - w)[nz] / np.abs(w)[nz]).max()))
         eng.close()
-    print("deterministic trainer fuzz: worst relative deviation of a weight from the oracle's %.2e" % worst)
+    print("trainer fuzz: worst relative deviation of a weight from the oracle's %.2e" % worst)
