@@ -80,7 +80,8 @@ int opal_adopt_weights_device(opal_ctx *ctx, float *d_w, uint64_t n_slots, uint6
  * 1 = non-temporal loads.  emit_qchunk: fragments per work-queue draw of opal_features (at most 64), 0 = default (32).
  * emit_fast: 1 = opal_features hashes short 2-bit packed fragments with its fast kernel (default), 0 = generic kernel only;
  * 2 / 3 = a measured, not adopted experiment (per-base term arrays for the run pattern, fragments of up to 256 / 512 bases;
- * canonical two-pattern geometry only, same output).  train_group: examples per group of opal_train_batch's deterministic mode, 0 = default (8192).                        */
+ * canonical two-pattern geometry only, same output); 4 = the fast kernels without the paired form of the gathered rows (two letters
+ * per LDS word where the row's positions allow it: the default; tests compare the two).  train_group: examples per group of opal_train_batch's deterministic mode, 0 = default (8192).                        */
 int opal_set_tuning(opal_ctx *ctx, int predict_nt, uint64_t emit_qchunk, int emit_fast, uint64_t train_group);
 
 /* VW behaviours that differ between versions, defaults in brackets:

@@ -39,7 +39,8 @@ struct Geom {
 //   [16]    murmur term of the decimal pattern index xor the name length (wave-uniform tail of every name of the pattern)
 //   [17]    0xf when the 16 positions are one run of consecutive positions, else 0
 //   [18]    4 * (pos_0 + 1): for a run, the offset of the one word that holds all 16 codes
-constexpr int FASTPAT_DW = 20;
+constexpr int FASTPAT_DW = 52;
+constexpr int FASTPAT_PAIR = 20;   // [20..48]: the row's paired form (PairRec in opal_kernels.hip, built by opal_set_patterns)
 
 // ------------------------------------------------------------------------------------------ byte helpers
 __device__ __forceinline__ uint32_t rc_byte(uint32_t c)

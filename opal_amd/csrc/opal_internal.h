@@ -15,6 +15,7 @@ struct opal_ctx {
     uint8_t *d_pos = nullptr;  // P*t positions, each < k <= 256
     uint32_t *d_fast = nullptr; // per-pattern records of the emit fast path (FASTPAT_DW dwords each), nullptr when the geometry has none
     bool fast_canonP = false;   // 3 <= P <= 9, pattern 0 a run of 16, the others gathered: emit_canonP_kernel<P>
+    int fast_pair = 0;          // the gathered rows can be read two letters to a word (block_addr_pair): 1, or 2 = with a spare word
     bool fast_canon2 = false;   // P == 2, pattern 0 a run of 16, pattern 1 gathered: the emit kernel's straight-line step
     int p0_run = -1;           // first position of pattern 0 when it is a run of consecutive positions, else -1
     // weights (VW regressor, compact `w` components)

@@ -142,6 +142,45 @@ __device__ __forceinline__ void zread9(uint32_t base, uint32_t r, const uint32_t
                    "=&s"(t0), "=&s"(t1)
                  : "s"(base), "s"(r), "s"(q[0]), "s"(q[1]), "s"(q[2]), "s"(q[3]), "s"(q[4]), "s"(q[5]), "s"(q[6]), "s"(q[7]) : "memory", "scc", "m0");
 }
+// zread1 + nine more in one batch (the paired form: pattern 0's word, a row's eight words and its spare)
+__device__ __forceinline__ void zread10(uint32_t base, uint32_t r, const uint32_t (&q)[9], uint32_t &xr, uint32_t (&x)[9])
+{
+    uint32_t t0, t1;
+    asm volatile("s_add_u32 %10, %12, %13\n\ts_mov_b32 m0, %10\n\t"
+                 "s_add_u32 %11, %12, %14\n\tds_read_addtid_b32 %0\n\ts_mov_b32 m0, %11\n\t"
+                 "s_add_u32 %10, %12, %15\n\tds_read_addtid_b32 %1\n\ts_mov_b32 m0, %10\n\t"
+                 "s_add_u32 %11, %12, %16\n\tds_read_addtid_b32 %2\n\ts_mov_b32 m0, %11\n\t"
+                 "s_add_u32 %10, %12, %17\n\tds_read_addtid_b32 %3\n\ts_mov_b32 m0, %10\n\t"
+                 "s_add_u32 %11, %12, %18\n\tds_read_addtid_b32 %4\n\ts_mov_b32 m0, %11\n\t"
+                 "s_add_u32 %10, %12, %19\n\tds_read_addtid_b32 %5\n\ts_mov_b32 m0, %10\n\t"
+                 "s_add_u32 %11, %12, %20\n\tds_read_addtid_b32 %6\n\ts_mov_b32 m0, %11\n\t"
+                 "s_add_u32 %10, %12, %21\n\tds_read_addtid_b32 %7\n\ts_mov_b32 m0, %10\n\t"
+                 "s_add_u32 %11, %12, %22\n\tds_read_addtid_b32 %8\n\ts_mov_b32 m0, %11\n\t"
+                 "s_nop 0\n\tds_read_addtid_b32 %9\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(xr), "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]), "=&v"(x[8]),
+                   "=&s"(t0), "=&s"(t1)
+                 : "s"(base), "s"(r), "s"(q[0]), "s"(q[1]), "s"(q[2]), "s"(q[3]), "s"(q[4]), "s"(q[5]), "s"(q[6]), "s"(q[7]), "s"(q[8]) : "memory", "scc", "m0");
+}
+// nine words in one batch (the paired form: a row's eight words and its spare)
+__device__ __forceinline__ void zread9w(uint32_t base, const uint32_t (&q)[9], uint32_t (&x)[9])
+{
+    uint32_t t0, t1;
+    asm volatile("s_add_u32 %9, %11, %12\n\ts_mov_b32 m0, %9\n\t"
+                 "s_add_u32 %10, %11, %13\n\tds_read_addtid_b32 %0\n\ts_mov_b32 m0, %10\n\t"
+                 "s_add_u32 %9, %11, %14\n\tds_read_addtid_b32 %1\n\ts_mov_b32 m0, %9\n\t"
+                 "s_add_u32 %10, %11, %15\n\tds_read_addtid_b32 %2\n\ts_mov_b32 m0, %10\n\t"
+                 "s_add_u32 %9, %11, %16\n\tds_read_addtid_b32 %3\n\ts_mov_b32 m0, %9\n\t"
+                 "s_add_u32 %10, %11, %17\n\tds_read_addtid_b32 %4\n\ts_mov_b32 m0, %10\n\t"
+                 "s_add_u32 %9, %11, %18\n\tds_read_addtid_b32 %5\n\ts_mov_b32 m0, %9\n\t"
+                 "s_add_u32 %10, %11, %19\n\tds_read_addtid_b32 %6\n\ts_mov_b32 m0, %10\n\t"
+                 "s_add_u32 %9, %11, %20\n\tds_read_addtid_b32 %7\n\ts_mov_b32 m0, %9\n\t"
+                 "s_nop 0\n\tds_read_addtid_b32 %8\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]), "=&v"(x[8]),
+                   "=&s"(t0), "=&s"(t1)
+                 : "s"(base), "s"(q[0]), "s"(q[1]), "s"(q[2]), "s"(q[3]), "s"(q[4]), "s"(q[5]), "s"(q[6]), "s"(q[7]), "s"(q[8]) : "memory", "scc", "m0");
+}
 // the block's table offset from the four words that hold its letters at bits 2-3, 4-5, 6-7, 8-9 (v_and + 3 v_and_or)
 // (left to the compiler the same expression takes 5 instructions: three v_and, one v_and_or, one v_or3)
 __device__ __forceinline__ uint32_t and_or(uint32_t x, uint32_t m, uint32_t acc)   // (x & m) | acc, m wave-uniform
@@ -154,6 +193,25 @@ __device__ __forceinline__ uint32_t block_addr(uint32_t x0, uint32_t x1, uint32_
 {
     return and_or(x3, 0x300u, and_or(x2, 0xc0u, and_or(x1, 0x30u, x0 & 0xcu)));
 }
+// The same from TWO words: each holds two of the block's letters, the first where it belongs (bits 2-3 / 6-7), the second
+// 2 (gap - 1) bits further up (gap = distance of the two positions): a rotate by a wave-uniform amount brings it to bits 4-5 / 8-9.
+// A row may have one pair whose letters lie too far apart for one word (1 row in 8 of ldpc.py's has one, 1 in 600 two): its second
+// letter comes from the row's SPARE word, read where the letter sits in place; the masks say which (m_a / m_b: 0x30 / 0x300, or 0 for
+// the pair the spare serves; m_s: the spare's letter when it belongs to this block, else 0).  Nine LDS reads per row instead of 16
+// for 7 (of 16) more VALU instructions: the emit kernels are LDS-bound.
+template <bool SPARE>
+__device__ __forceinline__ uint32_t block_addr_pair(uint32_t xa, uint32_t sa, uint32_t ma, uint32_t xb, uint32_t sb, uint32_t mb,
+                                                    uint32_t xs, uint32_t ms)
+{
+    const uint32_t ra = __builtin_amdgcn_alignbit(xa, xa, sa), rb = __builtin_amdgcn_alignbit(xb, xb, sb);
+    const uint32_t a = and_or(rb, mb, and_or(xb, 0xc0u, and_or(ra, ma, xa & 0xcu)));
+    return SPARE ? and_or(xs, ms, a) : a;
+}
+// PAIR (template argument of the straight-line kernels): 0 = one letter per word, 1 = two letters per word, every pair of every
+// row inside one word (a third of ldpc.py's numHash-8 geometries, 87 % of its numHash-1 ones), 2 = with the spare word (98 % / 99.8 %)
+// A gathered row in its paired form (opal_set_patterns): record words [FASTPAT_PAIR ..)
+struct PairRec { uint32_t w[9], rot[8], m2[8], ms[4]; };
+constexpr int PAIRREC_DW = 29;
 __device__ __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 // One step of 64 windows (flat index u0 + lane over the forward strand's W windows, then the reverse complement's).
@@ -355,8 +413,10 @@ __device__ __forceinline__ void emit_report_left(uint32_t *s_left, uint32_t left
 // is straight-line code (no pattern loop, no per-pattern dispatch), and the LDS round trips of the two patterns overlap:
 // pattern 0's word travels with the first half of pattern 1's gathers, the first six table reads with the second half.
 // MIXED: the one step per fragment whose lanes straddle the two strands reads both and picks per lane.
-template <bool MIXED, bool KT = false>
-__device__ __forceinline__ void canon2_step(uint32_t bf, uint32_t br, bool on_rc, uint32_t rq, const uint32_t (&q)[16], uint32_t tail0,
+// PAIR: pattern 1's letters come two to a word (q = a PairRec: see block_addr_pair and opal_set_patterns), so the step's ten
+// add-TID reads are one batch and the table reads follow in one go.
+template <bool MIXED, bool KT = false, int PAIR = 0>
+__device__ __forceinline__ void canon2_step(uint32_t bf, uint32_t br, bool on_rc, uint32_t rq, const uint32_t (&q)[PAIRREC_DW], uint32_t tail0,
                                             uint32_t tail1, uint32_t u, bool live, uint32_t mask, const uint32_t *tab,
                                             uint32_t *__restrict__ dst, uint32_t ktoff = 0u)
 {
@@ -377,7 +437,26 @@ __device__ __forceinline__ void canon2_step(uint32_t bf, uint32_t br, bool on_rc
     auto vread = [&](uint32_t q) { return *reinterpret_cast<const uint32_t __attribute__((address_space(3))) *>((uintptr_t)(vb + q)); };
     uint32_t a0[4], a1[4];
     uint32_t t00, t01, t02, t03;
-    if constexpr (KT) {
+    uint32_t xp[9];
+    if constexpr (PAIR != 0) {
+        const uint32_t qw[9] = {q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8]};
+        const uint32_t q8[8] = {q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7]};
+        xp[8] = 0u;
+        if constexpr (MIXED) {
+            x0 = vread(rq);
+#pragma unroll
+            for (int i = 0; i < (PAIR == 2 ? 9 : 8); i++) xp[i] = vread(qw[i]);
+        } else if constexpr (PAIR == 2) {
+            zread10(bf, rq, qw, x0, xp);
+        } else {
+            uint32_t x8[8];
+            zread9(bf, rq, q8, x0, x8);
+#pragma unroll
+            for (int i = 0; i < 8; i++) xp[i] = x8[i];
+        }
+#pragma unroll
+        for (int b = 0; b < 4; b++) a0[b] = ((x0 >> (8 * b)) & 0xffu) << 2;
+    } else if constexpr (KT) {
         // pattern 0's terms are per-base: window w's block b is base w + r + 4b: KT[w + r + 4b] (rq = 4 (r + 1))
         const uint32_t kq[4] = {ktoff + rq - 4u, ktoff + rq + 12u, ktoff + rq + 28u, ktoff + rq + 44u};
         uint32_t kx[4];
@@ -401,6 +480,19 @@ __device__ __forceinline__ void canon2_step(uint32_t bf, uint32_t br, bool on_rc
 #pragma unroll
         for (int b = 0; b < 4; b++) a0[b] = ((x0 >> (8 * b)) & 0xffu) << 2;
     }
+    if constexpr (PAIR != 0) {
+        static_assert(!KT, "the per-base term experiment has no paired form");
+        // q: [0..8] the nine words, [9..16] rotates, [17..24] second-letter masks, [25..28] spare masks
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            a1[b] = block_addr_pair<PAIR == 2>(xp[2 * b], q[9 + 2 * b], q[17 + 2 * b], xp[2 * b + 1], q[10 + 2 * b], q[18 + 2 * b], xp[8], q[25 + b]);
+        t00 = T(1024u + a0[0]); t01 = T(a0[1]); t02 = T(a0[2]); t03 = T(a0[3]);
+        const uint32_t t10 = T(1024u + a1[0]), t11 = T(a1[1]), t12 = T(a1[2]), t13 = T(a1[3]);
+        const uint32_t h0 = mm_fmix(mm_hk(mm_hk(mm_hk(t00, t01), t02), t03) ^ tail0) & mask;
+        const uint32_t h1 = mm_fmix(mm_hk(mm_hk(mm_hk(t10, t11), t12), t13) ^ tail1) & mask;
+        if (live) *reinterpret_cast<uint2 *>(dst + 2u * u) = make_uint2(h0, h1);
+        return;
+    }
     a1[0] = block_addr(x[0], x[1], x[2], x[3]);
     a1[1] = block_addr(x[4], x[5], x[6], x[7]);
     if constexpr (!KT) { t00 = T(1024u + a0[0]); t01 = T(a0[1]); t02 = T(a0[2]); t03 = T(a0[3]); }
@@ -419,7 +511,7 @@ __device__ __forceinline__ void canon2_step(uint32_t bf, uint32_t br, bool on_rc
     if (live) *reinterpret_cast<uint2 *>(dst + 2u * u) = make_uint2(h0, h1);
 }
 
-template <bool KT, int ZL>
+template <bool KT, int ZL, int PAIR = 0>
 __global__ __launch_bounds__(BLOCK) void emit_canon2_kernel(Batch B, Geom G, uint32_t mask, const uint64_t *__restrict__ out_off,
                                                              uint32_t *__restrict__ out_idx, uint64_t out_cap,
                                                              unsigned long long *__restrict__ queue, uint64_t qchunk)
@@ -434,9 +526,9 @@ __global__ __launch_bounds__(BLOCK) void emit_canon2_kernel(Batch B, Geom G, uin
     fill_kmer4_table(s_tab);
     typedef const uint32_t __attribute__((address_space(4))) *const_u32;
     const const_u32 f0 = (const_u32)(uintptr_t)G.fast, f1 = (const_u32)(uintptr_t)(G.fast + FASTPAT_DW);
-    uint32_t q[16];
+    uint32_t q[PAIRREC_DW];
 #pragma unroll
-    for (int i = 0; i < 16; i++) q[i] = f1[i];
+    for (int i = 0; i < PAIRREC_DW; i++) q[i] = (PAIR != 0 || i < 16) ? f1[(PAIR != 0 ? FASTPAT_PAIR : 0) + i] : 0u;
     const uint32_t rq = f0[18], tail0 = f0[16], tail1 = f1[16];
     uint32_t *zw = s_wave[wv];
     const uint32_t zfa = sgpr((uint32_t)(uintptr_t)zw), zra = zfa + ZL * 4u;
@@ -475,9 +567,9 @@ __global__ __launch_bounds__(BLOCK) void emit_canon2_kernel(Batch B, Geom G, uin
                 // the fragment's last step under EXEC = its live lanes only (18 of 64 at 200 bases): the LDS serves 32 lanes a
                 // pass and the table reads collide less with fewer lanes
                 if (u0 + WAVE > U && u >= U) continue;
-                if (u0 + WAVE <= W || S == 1) canon2_step<false, KT>(bf, 0u, false, rq, q, tail0, tail1, u, true, mask, s_tab, dst, KTOFF);
-                else if (u0 >= W) canon2_step<false, KT>(br, 0u, false, rq, q, tail0, tail1, u, true, mask, s_tab, dst, KTOFF);
-                else canon2_step<true, KT>(bf, br, u >= W, rq, q, tail0, tail1, u, true, mask, s_tab, dst, KTOFF);
+                if (u0 + WAVE <= W || S == 1) canon2_step<false, KT, PAIR>(bf, 0u, false, rq, q, tail0, tail1, u, true, mask, s_tab, dst, KTOFF);
+                else if (u0 >= W) canon2_step<false, KT, PAIR>(br, 0u, false, rq, q, tail0, tail1, u, true, mask, s_tab, dst, KTOFF);
+                else canon2_step<true, KT, PAIR>(bf, br, u >= W, rq, q, tail0, tail1, u, true, mask, s_tab, dst, KTOFF);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next fragment's staging stays behind these reads
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -495,7 +587,8 @@ __global__ __launch_bounds__(BLOCK) void emit_canon2_kernel(Batch B, Geom G, uin
 // travel with the previous pattern's gathers).  Pattern 0's one word rides with the first eight gathers of pattern 1 (zread9).
 typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t u2u __attribute__((ext_vector_type(2), aligned(4)));
-struct PatRec { uint32_t q[16]; uint32_t tail; };
+struct PatRec { uint32_t q[PAIRREC_DW]; uint32_t tail; };   // q: 16 word offsets, or a PairRec (PAIR)
+template <int PAIR>
 __device__ __forceinline__ PatRec load_patrec(uint64_t fast_base, int p)
 {
     // the base goes through an empty asm so that the loads below cannot be hoisted out of the step (and all records held at once)
@@ -504,11 +597,11 @@ __device__ __forceinline__ PatRec load_patrec(uint64_t fast_base, int p)
     const const_u32 fp = (const_u32)(uintptr_t)(fast_base + (uint64_t)p * (FASTPAT_DW * 4u));
     PatRec r;
 #pragma unroll
-    for (int i = 0; i < 16; i++) r.q[i] = fp[i];
+    for (int i = 0; i < PAIRREC_DW; i++) r.q[i] = (PAIR != 0 || i < 16) ? fp[(PAIR != 0 ? FASTPAT_PAIR : 0) + i] : 0u;
     r.tail = fp[16];
     return r;
 }
-template <int P, bool MIXED>
+template <int P, bool MIXED, int PAIR>
 __device__ __forceinline__ void canonP_step(uint32_t bf, uint32_t br, bool on_rc, uint64_t fast_base, uint32_t rq, uint32_t tail0, uint32_t u,
                                             bool live, uint32_t mask, const uint32_t *tab, uint32_t *__restrict__ dst)
 {
@@ -526,11 +619,45 @@ __device__ __forceinline__ void canonP_step(uint32_t bf, uint32_t br, bool on_rc
         }
     };
     uint32_t h[P];
-    PatRec rec = load_patrec(fast_base, 1);
+    PatRec rec = load_patrec<PAIR>(fast_base, 1);
 #pragma unroll
     for (int p = 1; p < P; p++) {
         PatRec nxt = rec;
-        if (p + 1 < P) nxt = load_patrec(fast_base, p + 1);        // in flight during this pattern's gathers
+        if (p + 1 < P) nxt = load_patrec<PAIR>(fast_base, p + 1);  // in flight during this pattern's gathers
+        if constexpr (PAIR != 0) {
+            // two letters to a word: eight reads (PAIR == 2: and the spare) are all of the row
+            constexpr int NW = PAIR == 2 ? 9 : 8;
+            const uint32_t qw[9] = {rec.q[0], rec.q[1], rec.q[2], rec.q[3], rec.q[4], rec.q[5], rec.q[6], rec.q[7], rec.q[8]};
+            const uint32_t q8[8] = {rec.q[0], rec.q[1], rec.q[2], rec.q[3], rec.q[4], rec.q[5], rec.q[6], rec.q[7]};
+            uint32_t xp[9], x8[8];
+            xp[8] = 0u;
+            uint32_t x0 = 0u;
+            if constexpr (MIXED) {
+                if (p == 1) x0 = vread(rq);
+#pragma unroll
+                for (int i = 0; i < NW; i++) xp[i] = vread(qw[i]);
+            } else if constexpr (PAIR == 2) {
+                if (p == 1) zread10(bf, rq, qw, x0, xp);           // pattern 0's word travels with pattern 1's
+                else zread9w(bf, qw, xp);
+            } else {
+                if (p == 1) zread9(bf, rq, q8, x0, x8);
+                else zread8(bf, q8, x8);
+#pragma unroll
+                for (int i = 0; i < 8; i++) xp[i] = x8[i];
+            }
+            if (p == 1) {
+                uint32_t a0[4];
+#pragma unroll
+                for (int b = 0; b < 4; b++) a0[b] = ((x0 >> (8 * b)) & 0xffu) << 2;
+                h[0] = mm_fmix(mm_hk(mm_hk(mm_hk(T(1024u + a0[0]), T(a0[1])), T(a0[2])), T(a0[3])) ^ tail0) & mask;
+            }
+            uint32_t a[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                a[b] = block_addr_pair<PAIR == 2>(xp[2 * b], rec.q[9 + 2 * b], rec.q[17 + 2 * b], xp[2 * b + 1], rec.q[10 + 2 * b], rec.q[18 + 2 * b], xp[8], rec.q[25 + b]);
+            const uint32_t t0 = T(1024u + a[0]), t1 = T(a[1]), t2 = T(a[2]), t3 = T(a[3]);
+            h[p] = mm_fmix(mm_hk(mm_hk(mm_hk(t0, t1), t2), t3) ^ rec.tail) & mask;
+        } else {
         const uint32_t qa[8] = {rec.q[0], rec.q[1], rec.q[2], rec.q[3], rec.q[4], rec.q[5], rec.q[6], rec.q[7]};
         const uint32_t qb[8] = {rec.q[8], rec.q[9], rec.q[10], rec.q[11], rec.q[12], rec.q[13], rec.q[14], rec.q[15]};
         uint32_t x[8];
@@ -553,6 +680,7 @@ __device__ __forceinline__ void canonP_step(uint32_t bf, uint32_t br, bool on_rc
         rd8(qb, x);
         const uint32_t t2 = T(block_addr(x[0], x[1], x[2], x[3])), t3 = T(block_addr(x[4], x[5], x[6], x[7]));
         h[p] = mm_fmix(mm_hk(mm_hk(mm_hk(t0, t1), t2), t3) ^ rec.tail) & mask;
+        }
         rec = nxt;
     }
     if (live) {                                                    // features u*P .. u*P+P-1: one run of P dwords
@@ -567,7 +695,7 @@ __device__ __forceinline__ void canonP_step(uint32_t bf, uint32_t br, bool on_rc
 
 // (tried: every step through per-lane addresses -- compiler-scheduled ds_read_b32, one v_add per gather, no M0 traffic, finer
 // waits -- instead of the add-TID batches: 4-13 % slower at numHash 4 and 8)
-template <int P>
+template <int P, int PAIR>
 __global__ __launch_bounds__(BLOCK) void emit_canonP_kernel(Batch B, Geom G, uint32_t mask, const uint64_t *__restrict__ out_off,
                                                              uint32_t *__restrict__ out_idx, uint64_t out_cap,
                                                              unsigned long long *__restrict__ queue, uint64_t qchunk)
@@ -618,9 +746,9 @@ __global__ __launch_bounds__(BLOCK) void emit_canonP_kernel(Batch B, Geom G, uin
                 const uint32_t u = u0 + (uint32_t)lane;
                 const uint32_t bf = zfa + u0 * 4u, br = zra + (u0 - W) * 4u;
                 if (u0 + WAVE > U && u >= U) continue;         // the last step under EXEC = its live lanes (see emit_canon2_kernel)
-                if (u0 + WAVE <= W || S == 1) canonP_step<P, false>(bf, 0u, false, fast_base, rq, tail0, u, true, mask, s_tab, dst);
-                else if (u0 >= W) canonP_step<P, false>(br, 0u, false, fast_base, rq, tail0, u, true, mask, s_tab, dst);
-                else canonP_step<P, true>(bf, br, u >= W, fast_base, rq, tail0, u, true, mask, s_tab, dst);
+                if (u0 + WAVE <= W || S == 1) canonP_step<P, false, PAIR>(bf, 0u, false, fast_base, rq, tail0, u, true, mask, s_tab, dst);
+                else if (u0 >= W) canonP_step<P, false, PAIR>(br, 0u, false, fast_base, rq, tail0, u, true, mask, s_tab, dst);
+                else canonP_step<P, true, PAIR>(bf, br, u >= W, fast_base, rq, tail0, u, true, mask, s_tab, dst);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next fragment's staging stays behind these reads
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1137,7 +1265,7 @@ extern "C" int opal_set_patterns(opal_ctx *ctx, const int32_t *pos, int P, int t
     OPAL_HIP_CHECK(ctx, hipMemcpy(ctx->d_pos, h.data(), h.size(), hipMemcpyHostToDevice));
     // emit fast path (see emit_fast): t == 16 and, inside every block of 4, position j at least j (true for ascending rows)
     if (ctx->d_fast) { OPAL_HIP_CHECK(ctx, hipFree(ctx->d_fast)); ctx->d_fast = nullptr; }
-    bool fast_ok = t == 16, canon2 = false;
+    bool fast_ok = t == 16, canon2 = false, pair_ok = true, spare_used = false;
     std::vector<uint32_t> fp((size_t)P * FASTPAT_DW, 0u);
     auto host_mm_k = [](uint32_t k1) { k1 *= 0xcc9e2d51u; k1 = (k1 << 15) | (k1 >> 17); return k1 * 0x1b873593u; };
     for (int p = 0; p < P && fast_ok; p++) {
@@ -1161,6 +1289,26 @@ extern "C" int opal_set_patterns(opal_ctx *ctx, const int32_t *pos, int P, int t
         r[16] = host_mm_k(digits) ^ (uint32_t)(t + (p < 10 ? 1 : 2));
         r[17] = runs;
         r[18] = (uint32_t)(4 * (pos[p * t] + 1));
+        // the paired form (block_addr_pair; record words FASTPAT_PAIR + [0..8] words, [9..16] rotates, [17..24] second-letter masks,
+        // [25..28] spare masks): word 2b + m serves letters 4b + 2m and 4b + 2m + 1 when the second lies 1 .. 14 - 2m positions
+        // behind the first (still inside the word's 16 bases); ONE pair of the row may fail that: the spare word serves its second letter
+        uint32_t *pr = r + FASTPAT_PAIR;
+        int failed = 0;
+        pr[8] = 0;                                                // no spare needed: any word of the window (its mask is 0)
+        for (int b = 0; b < 4; b++)
+            for (int m = 0; m < 2; m++) {
+                const int a = p * t + 4 * b + 2 * m, gap = pos[a + 1] - pos[a], w = 2 * b + m;
+                const bool ok = gap >= 1 && 2 * m + gap <= 14;
+                pr[w] = r[4 * b + 2 * m];
+                pr[9 + w] = ok ? (uint32_t)(2 * (gap - 1)) : 0u;
+                pr[17 + w] = ok ? (m ? 0x300u : 0x30u) : 0u;
+                if (!ok && failed++ == 0) {
+                    pr[8] = r[4 * b + 2 * m + 1];                 // the second letter in place: bits 4-5 (m = 0) or 8-9 (m = 1)
+                    pr[25 + b] = m ? 0x300u : 0x30u;
+                }
+            }
+        if (failed > 1) pair_ok = false;
+        if (failed == 1) spare_used = true;
     }
     if (fast_ok) {
         OPAL_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_fast, fp.size() * sizeof(uint32_t)));
@@ -1168,6 +1316,7 @@ extern "C" int opal_set_patterns(opal_ctx *ctx, const int32_t *pos, int P, int t
     }
     ctx->fast_canon2 = fast_ok && P == 2 && canon2;
     ctx->fast_canonP = fast_ok && P >= 3 && P <= 9 && canon2;   // a run followed by P - 1 gathered rows: emit_canonP_kernel<P>
+    ctx->fast_pair = !(fast_ok && canon2 && pair_ok) ? 0 : spare_used ? 2 : 1;   // the gathered rows' letters two to a word (2: a row needs its spare word)
     ctx->P = P; ctx->t = t; ctx->k = k;
     ctx->p0_run = pos[0];   // pattern 0 as a run of consecutive positions (Opal's first row: ldpc.py:83-85), else -1
     for (int j = 1; j < t; j++)
@@ -1379,17 +1528,21 @@ extern "C" int opal_features(opal_ctx *ctx, const uint8_t *d_reads, uint64_t rea
             // tune_emit_kt (experiment, opal_set_tuning emit_fast = 2 / 3): per-base term arrays for pattern 0, for fragments of up
             // to 256 bases (2) or EF_MAXLEN (3); what such a kernel does not take goes to the generic kernel
             const void *fn2 = ctx->tune_emit_kt == 2 ? (const void *)&emit_canon2_kernel<true, 320>
-                            : ctx->tune_emit_kt == 3 ? (const void *)&emit_canon2_kernel<true, EF_ZLEN> : (const void *)&emit_canon2_kernel<false, EF_ZLEN>;
+                            : ctx->tune_emit_kt == 3 ? (const void *)&emit_canon2_kernel<true, EF_ZLEN>
+                            : (ctx->fast_pair == 1 && ctx->tune_emit_kt != 4) ? (const void *)&emit_canon2_kernel<false, EF_ZLEN, 1>
+                            : (ctx->fast_pair == 2 && ctx->tune_emit_kt != 4) ? (const void *)&emit_canon2_kernel<false, EF_ZLEN, 2>
+                                                                              : (const void *)&emit_canon2_kernel<false, EF_ZLEN>;
             rc = grid_for(ctx, fn2, n, &grid);
             if (rc) return rc;
             uint64_t qc = draw_for(grid);
             void *args[] = {&B, &G, (void *)&mask, &d_out_off, &d_out_idx, &out_cap, &ctx->d_queue, &qc};
             OPAL_HIP_CHECK(ctx, hipLaunchKernel(fn2, dim3(grid), dim3(BLOCK), args, 0, ctx->stream));
         } else if (ctx->fast_canonP) {
-            const void *fnP = ctx->P == 3 ? (const void *)&emit_canonP_kernel<3> : ctx->P == 4 ? (const void *)&emit_canonP_kernel<4>
-                            : ctx->P == 5 ? (const void *)&emit_canonP_kernel<5> : ctx->P == 6 ? (const void *)&emit_canonP_kernel<6>
-                            : ctx->P == 7 ? (const void *)&emit_canonP_kernel<7> : ctx->P == 8 ? (const void *)&emit_canonP_kernel<8>
-                                                                                                : (const void *)&emit_canonP_kernel<9>;
+            const int pair = ctx->tune_emit_kt == 4 ? 0 : ctx->fast_pair;
+#define OPAL_CP(N) (pair == 1 ? (const void *)&emit_canonP_kernel<N, 1> : pair == 2 ? (const void *)&emit_canonP_kernel<N, 2> : (const void *)&emit_canonP_kernel<N, 0>)
+            const void *fnP = ctx->P == 3 ? OPAL_CP(3) : ctx->P == 4 ? OPAL_CP(4) : ctx->P == 5 ? OPAL_CP(5) : ctx->P == 6 ? OPAL_CP(6)
+                            : ctx->P == 7 ? OPAL_CP(7) : ctx->P == 8 ? OPAL_CP(8) : OPAL_CP(9);
+#undef OPAL_CP
             rc = grid_for(ctx, fnP, n, &grid);
             if (rc) return rc;
             uint64_t qc = draw_for(grid);

@@ -772,6 +772,67 @@ def test_straight_line_emit_kernels_for_every_pattern_count(amd, eng, oracle, P)
     eng.sync()
 
 
+def _pair_eligible(row):
+    """opal_set_patterns' rule for the paired form: inside every block of 4, letters (0,1) and (2,3) lie 1 .. 14 - 2m apart;
+    one pair of the row may fail that (the spare word serves it)."""
+    return sum(not (1 <= row[4 * b + 2 * m + 1] - row[4 * b + 2 * m] <= 14 - 2 * m) for b in range(4) for m in range(2)) <= 1
+
+
+@pytest.mark.parametrize("case", ["edge", "random2", "random5", "random9", "spare_first_pair", "spare_second_pair", "spare_last_block",
+                                  "two_far_pairs", "mixed_rows"])
+def test_paired_letter_emit_kernels(amd, eng, oracle, case):
+    """The emit kernels read a gathered row's letters two to a word (block_addr_pair, opal_set_patterns): rows at the rule's
+    limits (gaps of 14 and 12, a run block inside, rotate 0), random rows for numHash 1 / 4 / 8 (one row in eight needs the spare
+    word), rows whose one far pair sits on a block's first or second pair or in the last block (spare word, each mask), and rows
+    with two far pairs, alone and among paired ones, which must go the one-letter-per-word way.  Against the oracle, and the
+    paired form switched off (opal_set_tuning emit_fast = 4) against it switched on."""
+    import torch
+    rng = np.random.default_rng(sum(map(ord, case)))
+    k = 64
+    run = np.arange(16) + 3
+    edge = np.array([0, 14, 15, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 50, 51, 63])
+    two_far = np.array([0, 15, 16, 17, 18, 33, 34, 35] + list(range(36, 44)))
+
+    def random_eligible():
+        while True:
+            r = np.sort(rng.choice(k, size=16, replace=False))
+            if _pair_eligible(r):
+                return r
+
+    if case == "edge":
+        rows, want_pairs = [run, edge], True
+    elif case.startswith("random"):
+        rows, want_pairs = [run] + [random_eligible() for _ in range(int(case[6:]) - 1)], True
+    elif case == "spare_first_pair":
+        rows, want_pairs = [run, np.array([0, 15] + list(range(16, 30)))], True
+    elif case == "spare_second_pair":
+        rows, want_pairs = [run, np.array([0, 1, 2, 15] + list(range(16, 28)))], True
+    elif case == "spare_last_block":
+        rows, want_pairs = [run, np.array(list(range(4, 16)) + [44, 45, 46, 63]), np.array(list(range(0, 12)) + [20, 40, 41, 42])], True
+    elif case == "two_far_pairs":
+        rows, want_pairs = [run, two_far], False
+    else:
+        rows, want_pairs = [run, random_eligible(), two_far, edge], False
+    assert all(_pair_eligible(r) for r in rows[1:]) == want_pairs
+    pos = np.stack(rows).astype(np.int32)
+    eng.set_patterns(pos, k)
+    lens = [0, 63, 64, 65, 127, 128, 129, 191, 192, 193, 200, 256, 300, 511, 512, 513]
+    seqs = [bytes(rng.choice(ACGT, size=L)) for L in lens] + [bytes(rng.choice(ACGT, size=int(L))) for L in rng.integers(64, 400, size=40)]
+    seqs.append(bytes(rng.choice(ACGT, size=200)).lower())
+    batch = eng.upload(amd.PackedReads.from_sequences(seqs))
+    for reverse in (True, False):
+        eng.set_tuning()
+        idx, off = eng.features(batch, reverse, 31)
+        oidx, ooff = oracle.features_batch(seqs, k, pos, reverse, 31)
+        assert np.array_equal(off.cpu().numpy().view(np.uint64), ooff), (case, reverse)
+        assert np.array_equal(_u32(idx), oidx), (case, reverse)
+        eng.set_tuning(emit_fast=4)
+        idx4, _ = eng.features(batch, reverse, 31)
+        assert torch.equal(idx4, idx), (case, reverse)
+    eng.set_tuning()
+    eng.sync()
+
+
 def test_per_base_term_experiment_matches_the_shipped_emit_kernel(amd, eng, golden_dir):
     """opal_set_tuning(emit_fast = 2 | 3): emit_canon2_kernel with per-base term arrays for the run pattern ("Emit,
     round 3": measured, not adopted).  Same indices as the default kernel, for lengths either side of its 256-base variant's
