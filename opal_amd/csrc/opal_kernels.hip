@@ -212,6 +212,10 @@ __device__ __forceinline__ uint32_t block_addr_pair(uint32_t xa, uint32_t sa, ui
 // A gathered row in its paired form (opal_set_patterns): record words [FASTPAT_PAIR ..)
 struct PairRec { uint32_t w[9], rot[8], m2[8], ms[4]; };
 constexpr int PAIRREC_DW = 29;
+// which words of a row's record a kernel variant reads (the others never reach a register): PAIR 0 the 16 word offsets, PAIR 1
+// eight words and eight rotates, PAIR 2 the whole PairRec
+template <int PAIR>
+__device__ constexpr bool pairrec_used(int i) { return PAIR == 2 || (PAIR == 1 ? (i < 8 || (i >= 9 && i < 17)) : i < 16); }
 __device__ __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 // One step of 64 windows (flat index u0 + lane over the forward strand's W windows, then the reverse complement's).
@@ -485,7 +489,8 @@ __device__ __forceinline__ void canon2_step(uint32_t bf, uint32_t br, bool on_rc
         // q: [0..8] the nine words, [9..16] rotates, [17..24] second-letter masks, [25..28] spare masks
 #pragma unroll
         for (int b = 0; b < 4; b++)
-            a1[b] = block_addr_pair<PAIR == 2>(xp[2 * b], q[9 + 2 * b], q[17 + 2 * b], xp[2 * b + 1], q[10 + 2 * b], q[18 + 2 * b], xp[8], q[25 + b]);
+            a1[b] = block_addr_pair<PAIR == 2>(xp[2 * b], q[9 + 2 * b], PAIR == 1 ? 0x30u : q[17 + 2 * b], xp[2 * b + 1], q[10 + 2 * b],
+                                               PAIR == 1 ? 0x300u : q[18 + 2 * b], xp[8], q[25 + b]);   // (PAIR == 1: every pair inside its word, the masks are constants)
         t00 = T(1024u + a0[0]); t01 = T(a0[1]); t02 = T(a0[2]); t03 = T(a0[3]);
         const uint32_t t10 = T(1024u + a1[0]), t11 = T(a1[1]), t12 = T(a1[2]), t13 = T(a1[3]);
         const uint32_t h0 = mm_fmix(mm_hk(mm_hk(mm_hk(t00, t01), t02), t03) ^ tail0) & mask;
@@ -528,7 +533,7 @@ __global__ __launch_bounds__(BLOCK) void emit_canon2_kernel(Batch B, Geom G, uin
     const const_u32 f0 = (const_u32)(uintptr_t)G.fast, f1 = (const_u32)(uintptr_t)(G.fast + FASTPAT_DW);
     uint32_t q[PAIRREC_DW];
 #pragma unroll
-    for (int i = 0; i < PAIRREC_DW; i++) q[i] = (PAIR != 0 || i < 16) ? f1[(PAIR != 0 ? FASTPAT_PAIR : 0) + i] : 0u;
+    for (int i = 0; i < PAIRREC_DW; i++) q[i] = pairrec_used<PAIR>(i) ? f1[(PAIR != 0 ? FASTPAT_PAIR : 0) + i] : 0u;
     const uint32_t rq = f0[18], tail0 = f0[16], tail1 = f1[16];
     uint32_t *zw = s_wave[wv];
     const uint32_t zfa = sgpr((uint32_t)(uintptr_t)zw), zra = zfa + ZL * 4u;
@@ -578,6 +583,14 @@ __global__ __launch_bounds__(BLOCK) void emit_canon2_kernel(Batch B, Geom G, uin
     emit_report_left(&s_left, left, lane, queue);
 }
 
+// (Tried in round 3, after the paired letters had made the kernel VALU-bound: the draw's fragments hashed as ONE stream of windows --
+// two fragments staged in two LDS slots of 320 entries per strand, and when fewer than 64 windows of fragment A are left the step's
+// other lanes start fragment B's forward strand through the per-lane-address step, with a per-lane output pointer: 4.3 steps per
+// 200-base fragment instead of 5, the last of them no longer spent on 18 live lanes.  Correct (all parity tests), and worth 2 %:
+// cfg5 25.4 -> 24.9 ms, 200 bases 6.33 -> 6.40e11 hashes/s, 300 bases -2 %, 100 bases -11 % (no chaining below 64 windows per strand,
+// more bookkeeping per fragment): the second per-lane-address step per fragment, 6 instead of 7 waves per SIMD and the scalar state of
+// two fragments eat what the saved step gives.  Removed.  One lesson kept: fetched-ahead registers must be redefined at ONE place of
+// a loop; redefined on several paths they are copied on every back edge, which waits for the loads in flight at every step.)
 // ---- The canonical Opal geometry with numHash = 2 ... 8 (ldpc.py: pattern 0 a run of 16 positions, patterns 1 .. P-1 LDPC rows;
 // the reference CLI's default is --num-hash 8, P = 9: opal.py:534-536) gets the same treatment as numHash = 1: a step is
 // straight-line code over all P patterns (P is a template argument: no pattern loop, no per-pattern dispatch), the P hashes of a
@@ -597,7 +610,7 @@ __device__ __forceinline__ PatRec load_patrec(uint64_t fast_base, int p)
     const const_u32 fp = (const_u32)(uintptr_t)(fast_base + (uint64_t)p * (FASTPAT_DW * 4u));
     PatRec r;
 #pragma unroll
-    for (int i = 0; i < PAIRREC_DW; i++) r.q[i] = (PAIR != 0 || i < 16) ? fp[(PAIR != 0 ? FASTPAT_PAIR : 0) + i] : 0u;
+    for (int i = 0; i < PAIRREC_DW; i++) r.q[i] = pairrec_used<PAIR>(i) ? fp[(PAIR != 0 ? FASTPAT_PAIR : 0) + i] : 0u;
     r.tail = fp[16];
     return r;
 }
@@ -654,7 +667,8 @@ __device__ __forceinline__ void canonP_step(uint32_t bf, uint32_t br, bool on_rc
             uint32_t a[4];
 #pragma unroll
             for (int b = 0; b < 4; b++)
-                a[b] = block_addr_pair<PAIR == 2>(xp[2 * b], rec.q[9 + 2 * b], rec.q[17 + 2 * b], xp[2 * b + 1], rec.q[10 + 2 * b], rec.q[18 + 2 * b], xp[8], rec.q[25 + b]);
+                a[b] = block_addr_pair<PAIR == 2>(xp[2 * b], rec.q[9 + 2 * b], PAIR == 1 ? 0x30u : rec.q[17 + 2 * b], xp[2 * b + 1], rec.q[10 + 2 * b],
+                                                  PAIR == 1 ? 0x300u : rec.q[18 + 2 * b], xp[8], rec.q[25 + b]);
             const uint32_t t0 = T(1024u + a[0]), t1 = T(a[1]), t2 = T(a[2]), t3 = T(a[3]);
             h[p] = mm_fmix(mm_hk(mm_hk(mm_hk(t0, t1), t2), t3) ^ rec.tail) & mask;
         } else {
