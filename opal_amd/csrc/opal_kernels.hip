@@ -495,7 +495,8 @@ __device__ __forceinline__ void canon2_step(uint32_t bf, uint32_t br, bool on_rc
         const uint32_t t10 = T(1024u + a1[0]), t11 = T(a1[1]), t12 = T(a1[2]), t13 = T(a1[3]);
         const uint32_t h0 = mm_fmix(mm_hk(mm_hk(mm_hk(t00, t01), t02), t03) ^ tail0) & mask;
         const uint32_t h1 = mm_fmix(mm_hk(mm_hk(mm_hk(t10, t11), t12), t13) ^ tail1) & mask;
-        if (live) *reinterpret_cast<uint2 *>(dst + 2u * u) = make_uint2(h0, h1);
+        // (byte offset formed in 32 bits: the store then takes the wave-uniform base from SGPRs and one VGPR offset, no 64-bit add)
+        if (live) *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(dst) + (uint32_t)(u * 8u)) = make_uint2(h0, h1);
         return;
     }
     a1[0] = block_addr(x[0], x[1], x[2], x[3]);
@@ -513,7 +514,7 @@ __device__ __forceinline__ void canon2_step(uint32_t bf, uint32_t br, bool on_rc
     const uint32_t t12 = T(a1[2]), t13 = T(a1[3]);
     const uint32_t h0 = mm_fmix(mm_hk(mm_hk(mm_hk(t00, t01), t02), t03) ^ tail0) & mask;
     const uint32_t h1 = mm_fmix(mm_hk(mm_hk(mm_hk(t10, t11), t12), t13) ^ tail1) & mask;
-    if (live) *reinterpret_cast<uint2 *>(dst + 2u * u) = make_uint2(h0, h1);
+    if (live) *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(dst) + (uint32_t)(u * 8u)) = make_uint2(h0, h1);
 }
 
 template <bool KT, int ZL, int PAIR = 0>
@@ -698,7 +699,7 @@ __device__ __forceinline__ void canonP_step(uint32_t bf, uint32_t br, bool on_rc
         rec = nxt;
     }
     if (live) {                                                    // features u*P .. u*P+P-1: one run of P dwords
-        uint32_t *o = dst + u * (uint32_t)P;
+        uint32_t *o = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(dst) + (uint32_t)(u * (uint32_t)(4 * P)));   // (32-bit byte offset: SGPR base + one VGPR)
         int i = 0;
 #pragma unroll
         for (; i + 4 <= P; i += 4) { u4u v; v.x = h[i]; v.y = h[i + 1]; v.z = h[i + 2]; v.w = h[i + 3]; *reinterpret_cast<u4u *>(o + i) = v; }
