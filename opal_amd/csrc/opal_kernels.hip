@@ -197,8 +197,9 @@ __device__ __forceinline__ uint32_t block_addr(uint32_t x0, uint32_t x1, uint32_
 // 2 (gap - 1) bits further up (gap = distance of the two positions): a rotate by a wave-uniform amount brings it to bits 4-5 / 8-9.
 // A row may have one pair whose letters lie too far apart for one word (1 row in 8 of ldpc.py's has one, 1 in 600 two): its second
 // letter comes from the row's SPARE word, read where the letter sits in place; the masks say which (m_a / m_b: 0x30 / 0x300, or 0 for
-// the pair the spare serves; m_s: the spare's letter when it belongs to this block, else 0).  Nine LDS reads per row instead of 16
-// for 7 (of 16) more VALU instructions: the emit kernels are LDS-bound.
+// the pair the spare serves; m_s: the spare's letter when it belongs to this block, else 0).  Eight (nine with the spare)
+// LDS reads per row instead of 16, for 24 (28) VALU instructions per row instead of 16: the kernels were LDS-bound (91 % busy) when
+// this was built and sit at 93 % VALU issue / 82 % LDS since.
 template <bool SPARE>
 __device__ __forceinline__ uint32_t block_addr_pair(uint32_t xa, uint32_t sa, uint32_t ma, uint32_t xb, uint32_t sb, uint32_t mb,
                                                     uint32_t xs, uint32_t ms)
